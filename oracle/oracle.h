@@ -1,0 +1,106 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.
+ * C API of the CPU restatement (f64) of the reference's integrator path
+ * (camera.rs, hittable/, bsdf/ of chiefchewie/thu-acg-f2024-path-tracer).
+ * Parity status: the reference is Rust and cannot be built here (no cargo/rustc), it has
+ * no tests or golden vectors, and its RNG is unseedable — so this oracle is pinned by
+ * hand-derived known-answer values (a2, a18, a19, a20, a24), Philox known-answer
+ * vectors and identities only. Against the Rust binary itself: "parity unpinned".
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library. The builder calls mirror include/pt_amd.h one-to-one so that one scene
+ * description can be replayed onto both.
+ *
+ * All handles are small non-negative ints local to one orc_scene; -1 = error
+ * (orc_last_error()). Not thread-safe per scene; orc_render fans out with OpenMP.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+
+typedef struct orc_camera {      /* camera.rs:23-36 */
+    double aspect_ratio;
+    uint32_t image_width, samples_per_pixel, max_depth, env_is_map;
+    double vfov;
+    double look_from[3], look_at[3], vup[3];
+    double blur_strength, focal_length, defocus_angle;
+    double env_color[3];
+    int32_t env_tex;             /* image texture handle when env_is_map */
+    int32_t _pad;
+} orc_camera;
+
+const char* orc_last_error(void);
+orc_scene* orc_scene_create(void);
+void orc_scene_destroy(orc_scene*);
+
+/* textures (texture.rs) */
+int orc_tex_solid_rgb(orc_scene*, double r, double g, double b);
+int orc_tex_solid_f(orc_scene*, double v);
+int orc_tex_checker(orc_scene*, double scale, int tex1, int tex2);
+int orc_tex_image_rgb8(orc_scene*, uint32_t w, uint32_t h, const uint8_t* rgb);
+/* materials (bsdf/, material.rs:150-191) */
+int orc_mat_diffuse(orc_scene*, int color_tex, int normal_map_tex /* -1 = none */);
+int orc_mat_metal(orc_scene*, int color_tex, int rough_tex);
+int orc_mat_glass(orc_scene*, int color_tex, int rough_tex, double anisotropic, double ior);
+int orc_mat_principled(orc_scene*, int color_tex, const double params[11]);
+int orc_mat_light(orc_scene*, int emission_tex);
+/* geometry (hittable/) */
+int orc_sphere(orc_scene*, double radius, const double p1[3], const double p2[3], int mat);
+int orc_quad(orc_scene*, const double q[3], const double u[3], const double v[3], int mat);
+int orc_cuboid(orc_scene*, const double a[3], const double b[3], int mat);
+int orc_mesh(orc_scene*, double scale, uint32_t n_pos, const float* pos, uint32_t n_idx,
+             const uint32_t* idx, uint32_t n_nrm, const float* nrm, uint32_t n_uv, const float* uv, int mat);
+int orc_instance(orc_scene*, int obj, const double axis[3], double angle, const double translation[3]);
+/* world (world.rs) */
+int orc_world_add_object(orc_scene*, int obj);
+int orc_world_add_light(orc_scene*, int obj);
+int orc_world_build(orc_scene*);
+uint32_t orc_world_prim_count(orc_scene*);
+
+/* asset ingest restated (tobj 4.0.2 / image 0.25.5 behaviour; "parity unpinned") */
+int orc_load_obj(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx,
+                 float** uv, uint32_t* n_uv);
+int orc_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);
+void orc_free(void*);
+/* decoded images the oracle cannot decode itself (JPEG/PNG), looked up by the built-in
+ * scenes under the file name the reference opens (e.g. "envmap.jpg", "bricks/color.png") */
+int orc_register_image(orc_scene*, const char* name, uint32_t w, uint32_t h, const uint8_t* rgb);
+
+/* built-in scenes with the literals of main.rs (3 = Cornell :134-236, 5 = BSDF grid :276-369,
+ * 6 = everything :371-532, plus 1,2,4,7). asset_dir holds bunny.obj etc.; env_rgb8 (may be
+ * NULL) overrides the environment image (used for the JPEG the oracle cannot decode). */
+int orc_build_scene(orc_scene*, int scene_id, uint32_t width, uint32_t spp, const char* asset_dir,
+                    const uint8_t* env_rgb8, uint32_t env_w, uint32_t env_h, uint64_t scene_seed,
+                    orc_camera* out_cam);
+
+/* camera.rs:51-77; out6x3 = forward,right,up,pixel00,pixel_du,pixel_dv */
+int orc_camera_init(const orc_camera*, double out6x3[18], uint32_t* image_height);
+
+/* camera.rs:79-126 without gamma/quantise: accum[(y*W+x)*3+c] += sum over samples
+ * [spp_begin, spp_end) of trace(y, x), summed in sample order. counters (may be NULL):
+ * {segments, box_tests, prim_tests, samples}. nthreads<=0 -> all cores. */
+int orc_render(orc_scene*, const orc_camera*, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
+               double* accum, uint64_t counters[4], int nthreads);
+/* one sample of one pixel; dump (may be NULL) receives up to max_rec records of
+ * {t, prim_id, px,py,pz, tx,ty,tz} (8 doubles each); returns the number of segments */
+int orc_trace_sample(orc_scene*, const orc_camera*, uint64_t seed, uint32_t pixel, uint32_t sample,
+                     double radiance[3], double* dump, uint32_t max_rec);
+/* camera.rs:109-114,128-130 */
+void orc_resolve_u8(const double* accum, uint32_t n_pixels, uint32_t total_spp, uint8_t* rgb8);
+
+/* scalar probes used by the known-answer tests */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);
+double orc_probe(int which, const double* args);
+/* primitive-level probe: closest hit of one ray against the built world.
+ * out = {hit(0/1), t, prim_id, u, v, front_face, px,py,pz, gnx,gny,gnz, snx,sny,snz} */
+int orc_intersect(orc_scene*, const double origin[3], const double dir[3], double time, double out[15]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

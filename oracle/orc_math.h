@@ -1,0 +1,152 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// CPU restatement of the reference's f64 vector maths (glam 0.29.2 semantics,
+// Cargo.lock:372-373; the crate source is NOT in /root/reference, so these follow
+// glam's documented behaviour and are "parity unpinned" — see DESIGN.md §oracle).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+// anything under oracle/. The product (thu-acg-f2024-path-tracer_amd/) never does.
+//
+// Arithmetic contract: plain IEEE-754 binary64, one rounding per written
+// operation, NO fused multiply-add (build with -ffp-contract=off), evaluation
+// order exactly as written (it mirrors Rust's left-to-right order in the cited
+// reference expressions).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+namespace orc {
+
+constexpr double PI = 3.14159265358979323846264338327950288;  // std::f64::consts::PI
+
+struct V3 {
+    double x, y, z;
+};
+inline V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+inline V3 splat(double s) { return V3{s, s, s}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+inline V3 operator/(V3 a, V3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline V3 operator-(double s, V3 a) { return {s - a.x, s - a.y, s - a.z}; }  // `1.0 - r0`
+inline V3& operator+=(V3& a, V3 b) { a = a + b; return a; }
+inline V3& operator*=(V3& a, V3 b) { a = a * b; return a; }
+inline V3& operator/=(V3& a, double s) { a = a / s; return a; }
+inline bool is_zero(V3 a) { return a.x == 0.0 && a.y == 0.0 && a.z == 0.0; }
+
+// glam DVec3::dot / cross / length / normalize (normalize multiplies by 1/len).
+inline double dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+inline V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+inline double length_squared(V3 a) { return dot(a, a); }
+inline double length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalize(V3 a) { return a * (1.0 / length(a)); }
+
+// Rust f64::min/max ignore a NaN operand (std::fmin/fmax do the same).
+inline double fmin2(double a, double b) { return std::fmin(a, b); }
+inline double fmax2(double a, double b) { return std::fmax(a, b); }
+inline V3 vmin(V3 a, V3 b) { return {fmin2(a.x, b.x), fmin2(a.y, b.y), fmin2(a.z, b.z)}; }
+inline V3 vmax(V3 a, V3 b) { return {fmax2(a.x, b.x), fmax2(a.y, b.y), fmax2(a.z, b.z)}; }
+inline double max_element(V3 a) { return fmax2(a.x, fmax2(a.y, a.z)); }
+inline double min_element(V3 a) { return fmin2(a.x, fmin2(a.y, a.z)); }
+// Rust f64::clamp: NaN stays NaN.
+inline double clampd(double x, double lo, double hi) {
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+// Rust f64::signum: +1 for +0.0, -1 for -0.0, NaN for NaN.
+inline double signum(double x) {
+    if (std::isnan(x)) return x;
+    return std::signbit(x) ? -1.0 : 1.0;
+}
+// powi(n) as LLVM expands it for constant n (square-and-multiply): x^2, x^5.
+inline double powi2(double x) { return x * x; }
+inline double powi5(double x) {
+    double x2 = x * x;
+    double x4 = x2 * x2;
+    return x * x4;
+}
+// glam DVec3::lerp (0.29): a*(1-s) + b*s ; glam FloatExt::lerp for f64: a + (b-a)*s.
+inline V3 vlerp(V3 a, V3 b, double s) { return a * (1.0 - s) + b * s; }
+inline double flerp(double a, double b, double s) { return a + (b - a) * s; }
+// glam reflect / refract (refract returns ZERO on total internal reflection).
+inline V3 reflect(V3 i, V3 n) { return i - n * (2.0 * dot(i, n)); }
+inline V3 refract(V3 i, V3 n, double eta) {
+    double n_dot_i = dot(n, i);
+    double k = 1.0 - eta * eta * (1.0 - n_dot_i * n_dot_i);
+    if (k >= 0.0) return eta * i - (eta * n_dot_i + std::sqrt(k)) * n;
+    return V3{0.0, 0.0, 0.0};
+}
+// vec3.rs:41  Rec.709 luma
+inline double luminance(V3 c) { return 0.2126 * c.x + 0.7152 * c.y + 0.0722 * c.z; }
+
+// ---- quaternions (glam DQuat, xyzw) -------------------------------------------------
+struct Quat {
+    double x, y, z, w;
+};
+inline Quat quat_normalize(Quat q) {
+    double len = std::sqrt((q.x * q.x) + (q.y * q.y) + (q.z * q.z) + (q.w * q.w));
+    double r = 1.0 / len;
+    return {q.x * r, q.y * r, q.z * r, q.w * r};
+}
+inline Quat quat_inverse(Quat q) { return {-q.x, -q.y, -q.z, q.w}; }  // conjugate (unit quat)
+inline Quat quat_from_axis_angle(V3 axis, double angle) {
+    double s = std::sin(angle * 0.5), c = std::cos(angle * 0.5);
+    V3 v = axis * s;
+    return {v.x, v.y, v.z, c};
+}
+// glam DQuat * DVec3
+inline V3 quat_mul_vec3(Quat q, V3 rhs) {
+    double w = q.w;
+    V3 b{q.x, q.y, q.z};
+    double b2 = dot(b, b);
+    return rhs * (w * w - b2) + b * (dot(rhs, b) * 2.0) + cross(b, rhs) * (w * 2.0);
+}
+// vec3.rs:23-29  shortest-arc rotation taking `input` onto +z
+inline Quat get_rotation_to_z(V3 input) {
+    if (input.z < -0.99999) return {1.0, 0.0, 0.0, 0.0};
+    return quat_normalize(Quat{input.y, -input.x, 0.0, 1.0 + input.z});
+}
+// sampling.rs:8-16
+inline V3 to_local(V3 normal, V3 w) { return quat_mul_vec3(get_rotation_to_z(normal), w); }
+inline V3 to_world(V3 normal, V3 w) {
+    return quat_mul_vec3(quat_inverse(get_rotation_to_z(normal)), w);
+}
+
+// ---- rigid transform (instance.rs:20-30: M = T * R(axis, angle)) ---------------------
+// Columns of R as glam's quat_to_axes builds them. The inverse is the ANALYTIC rigid
+// inverse (R^T, -(R^T t)); the reference calls the general DMat4::inverse() per ray
+// (instance.rs:36-37) which differs by ulps — documented deviation.
+struct Rigid {
+    V3 c0, c1, c2, t;      // forward: p' = t + (c2*z + (c1*y + c0*x))
+    V3 i0, i1, i2, it;     // inverse, same form
+};
+inline V3 xform_vector(V3 c0, V3 c1, V3 c2, V3 v) {
+    V3 r = c0 * v.x;
+    r = c1 * v.y + r;
+    r = c2 * v.z + r;
+    return r;
+}
+inline V3 xform_point(V3 c0, V3 c1, V3 c2, V3 t, V3 p) { return t + xform_vector(c0, c1, c2, p); }
+inline Rigid rigid_from_rotation_translation(Quat q, V3 t) {
+    double x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    double xx = q.x * x2, xy = q.x * y2, xz = q.x * z2;
+    double yy = q.y * y2, yz = q.y * z2, zz = q.z * z2;
+    double wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+    Rigid m;
+    m.c0 = {1.0 - (yy + zz), xy + wz, xz - wy};
+    m.c1 = {xy - wz, 1.0 - (xx + zz), yz + wx};
+    m.c2 = {xz + wy, yz - wx, 1.0 - (xx + yy)};
+    m.t = t;
+    m.i0 = {m.c0.x, m.c1.x, m.c2.x};
+    m.i1 = {m.c0.y, m.c1.y, m.c2.y};
+    m.i2 = {m.c0.z, m.c1.z, m.c2.z};
+    m.it = -xform_vector(m.i0, m.i1, m.i2, t);
+    return m;
+}
+
+}  // namespace orc
