@@ -1,0 +1,235 @@
+// Device-side primitive intersection (sphere / quad / triangle, optionally under a rigid
+// instance), hit-record reconstruction, light-list sampling and camera-ray generation.
+// Formulas and comparison strictness follow hittable/{sphere,quad,mesh,instance,hit_info}.rs
+// and camera.rs:133-168 operation by operation (see pt_dev_math.h for the contract).
+#pragma once
+#include "pt_dev_bsdf.h"
+
+namespace pt {
+
+struct RayD {
+    V3 o, d;   // d normalised (ray.rs:23-29)
+    double time;
+};
+PT_DEV V3 ray_at(const RayD& r, double t) { return r.o + r.d * t; }
+PT_DEV RayD make_ray(V3 o, V3 d, double time) { return RayD{o, normalize(d), time}; }
+// instance.rs:36-38 with the analytic rigid inverse
+PT_DEV RayD ray_to_local(const InstD& m, const RayD& r) {
+    return make_ray(xform_point(m.i0, m.i1, m.i2, m.it, r.o), xform_vector(m.i0, m.i1, m.i2, r.d), r.time);
+}
+
+// sphere.rs:64-87 — open interval (t_min, +inf)
+PT_DEV bool hit_sphere(const SphereD& s, const RayD& r, double t_min, double& t, V3& center) {
+    center = ld3(s.p1) + (ld3(s.p2) - ld3(s.p1)) * r.time;
+    V3 l = center - r.o;
+    double sd = dot(l, r.d);
+    double l2 = length_squared(l);
+    double r2 = s.r * s.r;
+    if (sd < 0.0 && l2 > r2) return false;
+    double d2 = l2 - sd * sd;
+    if (d2 > r2) return false;
+    double q = sqrt(r2 - d2);
+    t = l2 > r2 ? sd - q : sd + q;
+    if (t <= t_min || t >= D_INF) return false;
+    return true;
+}
+// quad.rs:40-59 — closed interval [t_min, +inf]
+PT_DEV bool hit_quad(const QuadD& qd, const RayD& r, double t_min, double& t, double& alpha, double& beta) {
+    V3 n = ld3(qd.n);
+    double nd = dot(n, r.d);
+    if (fabs(nd) < 1e-8) return false;
+    t = (qd.d - dot(n, r.o)) / nd;
+    if (!(t_min <= t && t <= D_INF)) return false;
+    V3 p = ray_at(r, t) - ld3(qd.q);
+    V3 w = ld3(qd.w);
+    alpha = dot(w, cross(p, ld3(qd.v)));
+    beta = dot(w, cross(ld3(qd.u), p));
+    if (!(alpha >= 0.0 && alpha <= 1.0) || !(beta >= 0.0 && beta <= 1.0)) return false;
+    return true;
+}
+// mesh.rs:50-82 Moeller-Trumbore — closed interval
+PT_DEV bool hit_tri(const TriD& tr, const RayD& r, double t_min, double& t, double& u, double& v) {
+    V3 v0 = ld3(tr.v0);
+    V3 edge1 = ld3(tr.v1) - v0, edge2 = ld3(tr.v2) - v0;
+    V3 h = cross(r.d, edge2);
+    double a = dot(edge1, h);
+    if (fabs(a) < 1e-8) return false;
+    double f = 1.0 / a;
+    V3 s = r.o - v0;
+    u = f * dot(s, h);
+    if (!(u >= 0.0 && u <= 1.0)) return false;
+    V3 q = cross(s, edge1);
+    v = f * dot(r.d, q);
+    if (v < 0.0 || u + v > 1.0) return false;
+    t = f * dot(edge2, q);
+    if (!(t_min <= t && t <= D_INF)) return false;
+    return true;
+}
+
+// hit_info.rs:57-67
+PT_DEV void tangent_basis(V3 n, V3& tangent, V3& bitangent) {
+    V3 a = fabs(n.x) > 0.9 ? V3{0.0, 1.0, 0.0} : V3{1.0, 0.0, 0.0};
+    tangent = normalize(cross(n, a));
+    bitangent = cross(n, tangent);
+}
+// HitInfo::new hit_info.rs:16-55
+PT_DEV void finish_hit(const SceneD& sc, const RayD& r, V3 point, V3 normal, double dist, uint32_t mat, double u,
+                       double v, HitD& h) {
+    h.front = dot(r.d, normal) < 0.0;
+    V3 nn = normalize(normal);
+    h.gn = h.front ? nn : -nn;
+    int32_t nm = sc.mats[mat].nmap_tex;
+    if (nm >= 0) {
+        V3 m = 2.0 * tex_image(sc, sc.tex[nm], u, v) - splat(1.0);
+        V3 t, b;
+        tangent_basis(h.gn, t, b);
+        h.sn = normalize(m.x * t + m.y * b + m.z * h.gn);
+    } else {
+        h.sn = h.gn;
+    }
+    h.point = point;
+    h.dist = dist;
+    h.mat = mat;
+    h.u = u;
+    h.v = v;
+}
+
+// Rebuilds the reference's HitInfo for primitive `gid` known to be hit by `world_ray`.
+// Re-runs that one primitive's intersection (same arithmetic as the traversal kernel, so the
+// same t/u/v bits), then applies Instance::intersects' world transform (instance.rs:43-53, Q1).
+PT_DEV bool reconstruct_hit(const SceneD& sc, const RayD& world_ray, uint32_t gid, double t_min, HitD& h) {
+    const PrimRef pr = sc.prims[gid];
+    RayD r = world_ray;
+    if (pr.inst >= 0) r = ray_to_local(sc.insts[pr.inst], world_ray);
+    const uint32_t kind = pr.kind & 0xFFu;
+    if (kind == PRIM_SPHERE) {
+        double t;
+        V3 c;
+        if (!hit_sphere(sc.spheres[pr.index], r, t_min, t, c)) return false;
+        V3 point = ray_at(r, t);
+        V3 normal = normalize(point - c);
+        double theta = acos(-normal.y);                       // sphere.rs:52-56
+        double phi = atan2(-normal.z, normal.x) + D_PI;
+        finish_hit(sc, r, point, normal, t, pr.mat, phi / (2.0 * D_PI), theta / D_PI, h);
+    } else if (kind == PRIM_QUAD) {
+        double t, a, b;
+        const QuadD& q = sc.quads[pr.index];
+        if (!hit_quad(q, r, t_min, t, a, b)) return false;
+        finish_hit(sc, r, ray_at(r, t), ld3(q.n), t, pr.mat, a, b, h);
+    } else {
+        double t, u, v;
+        const TriD& tr = sc.tris[pr.index];
+        if (!hit_tri(tr, r, t_min, t, u, v)) return false;
+        V3 v0 = ld3(tr.v0);
+        V3 edge1 = ld3(tr.v1) - v0, edge2 = ld3(tr.v2) - v0;
+        double w = 1.0 - u - v;
+        V3 normal;
+        double tu = u, tv = v;
+        if (pr.kind & PRIM_HAS_NORMALS) {                    // mesh.rs:85-87
+            const TriAttr& at = sc.tri_attr[pr.index];
+            normal = normalize(ld3(at.n[0]) * w + ld3(at.n[1]) * u + ld3(at.n[2]) * v);
+        } else {
+            normal = normalize(cross(edge1, edge2));          // flat shading :88
+        }
+        if (pr.kind & PRIM_HAS_UVS) {                        // mesh.rs:91-99
+            const TriAttr& at = sc.tri_attr[pr.index];
+            tu = at.uv[0][0] * w + at.uv[1][0] * u + at.uv[2][0] * v;
+            tv = at.uv[0][1] * w + at.uv[1][1] * u + at.uv[2][1] * v;
+        }
+        finish_hit(sc, r, ray_at(r, t), normal, t, pr.mat, tu, tv, h);
+    }
+    if (pr.inst >= 0) {
+        const InstD& m = sc.insts[pr.inst];
+        h.point = xform_point(m.c0, m.c1, m.c2, m.t, h.point);
+        h.gn = normalize(xform_vector(m.c0, m.c1, m.c2, h.gn));
+    }
+    return true;
+}
+
+// ---- lights list: HittableList::sample / pdf (list.rs:78-96) over quads and spheres -------
+PT_DEV V3 lights_sample(const SceneD& sc, V3 origin, double time, Rng& rng) {
+    uint32_t i = rng_index(rng, sc.n_lights);
+    const Entry e = sc.entries[sc.lights[i]];
+    const PrimRef pr = sc.prims[e.first_prim];
+    double a = rng_f64(rng), b = rng_f64(rng);
+    if (e.kind == ENTRY_QUAD) {                               // quad.rs:80-86
+        const QuadD& q = sc.quads[pr.index];
+        V3 point = ld3(q.q) + ld3(q.u) * a + ld3(q.v) * b;
+        return normalize(point - origin);
+    }
+    const SphereD& s = sc.spheres[pr.index];                  // sphere.rs:110-122
+    double theta = 2.0 * D_PI * a;
+    double phi = acos(2.0 * b - 1.0);
+    double x = sin(phi) * cos(theta), y = sin(phi) * sin(theta), z = cos(phi);
+    V3 center = ld3(s.p1) + (ld3(s.p2) - ld3(s.p1)) * time;
+    V3 point = center + V3{x, y, z} * s.r;
+    return normalize(point - origin);
+}
+PT_DEV double lights_pdf(const SceneD& sc, V3 origin, V3 direction, double time) {
+    if (sc.n_lights == 0) return 0.0;
+    RayD r = make_ray(origin, direction, time);
+    double sum = 0.0;
+    for (uint32_t i = 0; i < sc.n_lights; ++i) {
+        const Entry e = sc.entries[sc.lights[i]];
+        const PrimRef pr = sc.prims[e.first_prim];
+        double pdf = 0.0;
+        if (e.kind == ENTRY_QUAD) {                           // quad.rs:88-98 (interval [0, inf])
+            const QuadD& q = sc.quads[pr.index];
+            double t, al, be;
+            if (hit_quad(q, r, 0.0, t, al, be)) {
+                HitD h;
+                finish_hit(sc, r, ray_at(r, t), ld3(q.n), t, pr.mat, al, be, h);
+                double area = length(cross(ld3(q.u), ld3(q.v)));
+                double cos_theta = fabs(dot(r.d, h.sn));
+                pdf = (h.dist * h.dist) / (cos_theta * area);
+            }
+        } else {                                              // sphere.rs:124-135
+            const SphereD& s = sc.spheres[pr.index];
+            double t;
+            V3 c;
+            if (hit_sphere(s, r, 0.0, t, c)) {
+                double r2 = s.r * s.r;
+                V3 center = ld3(s.p1) + (ld3(s.p2) - ld3(s.p1)) * time;
+                double solid_angle = 2.0 * D_PI * sqrt(1.0 - r2 / length_squared(center - origin));
+                pdf = 1.0 / solid_angle;
+            }
+        }
+        sum += pdf;
+    }
+    return sum / (double)sc.n_lights;
+}
+
+// ---- camera.rs:133-168 -----------------------------------------------------------------
+PT_DEV void random_offsets(Rng& rng, double& ox, double& oy) {
+    uint64_t a, b;
+    rng_u64x2(rng, a, b);
+    double radius = sqrt(u64_to_unit(a));
+    double angle = u64_to_unit(b) * 2.0 * D_PI;
+    double sn, cs;
+    sincos(angle, &sn, &cs);
+    ox = radius * cs;
+    oy = radius * sn;
+}
+PT_DEV RayD generate_ray(const CamD& cam, uint32_t row, uint32_t col, Rng& rng) {
+    double bx, by;
+    random_offsets(rng, bx, by);
+    bx = bx * cam.blur_strength;
+    by = by * cam.blur_strength;
+    V3 sample_location = ld3(cam.pixel00) + (ld3(cam.pixel_dv) * ((double)row + bx)) + (ld3(cam.pixel_du) * ((double)col + by));
+    double px, py;
+    random_offsets(rng, px, py);
+    V3 origin = ld3(cam.center) + (ld3(cam.dof_right) * px) + (ld3(cam.dof_up) * py);
+    double time = rng_f64(rng);
+    return make_ray(origin, sample_location - origin, time);
+}
+// camera.rs:140-151
+PT_DEV V3 sample_environment(const SceneD& sc, const CamD& cam, V3 d) {
+    if (!cam.env_is_map) return ld3(cam.env_color);
+    double theta = acos(d.y);
+    double phi = atan2(d.z, d.x);
+    double u = (phi + D_PI) / (2.0 * D_PI);
+    double v = 1.0 - theta / D_PI;
+    return tex_image(sc, sc.tex[cam.env_tex], u, v);
+}
+
+}  // namespace pt

@@ -1,0 +1,347 @@
+// Wavefront path-tracing stages for gfx950 (MI355X). One lane = one resident path.
+//
+//   k_init     K1 raygen       camera.rs:153-168  fills the pool with the first sample of every slot
+//   k_extend   K2 closest hit  world.rs:47-62 -> bvh.rs:123-164 -> sphere/quad/mesh/instance.rs
+//   k_shade    K3+K4+K1'       camera.rs:177-226 body: miss/env, emission, RR, one-sample MIS,
+//                              BSDF sample+pdf+eval, next ray; finished paths are regenerated in place
+//   k_resolve  K6 (sum part)   camera.rs:106-109: per-pixel sum of the slot accumulators
+//
+// All kernels are persistent-thread style: a fixed grid sized to the machine walks the pool
+// with a grid-stride loop. No MFMA anywhere — this is branchy f64 scalar work bounded by
+// VALU issue and L2 latency, with the path pool streaming through HBM once per stage.
+#include <hip/hip_runtime.h>
+
+#include "pt_dev_geom.h"
+#include "pt_kernels.h"
+
+namespace pt {
+
+constexpr int BLOCK = 256;
+
+// ---------------------------------------------------------------------------------------
+// Closest-hit traversal. Two-level BVH2 walked with one per-lane stack held in LDS
+// (stack[level][lane]: a wave touches 64 consecutive dwords per level -> conflict free).
+// The result is tree-independent: minimum t; on an exact tie the larger global primitive id
+// wins, so any builder/visit order gives the reference's hit.
+// ---------------------------------------------------------------------------------------
+struct Closest {
+    double t;
+    uint32_t id;
+};
+PT_DEV void consider(Closest& best, double t, uint32_t id) {
+    if (t < best.t || (t == best.t && id > best.id)) {
+        best.t = t;
+        best.id = id;
+    }
+}
+PT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv, double t_min, double t_max, double& t_near) {
+    double t1x = ((double)lo[0] - o.x) * inv.x, t2x = ((double)hi[0] - o.x) * inv.x;
+    double t1y = ((double)lo[1] - o.y) * inv.y, t2y = ((double)hi[1] - o.y) * inv.y;
+    double t1z = ((double)lo[2] - o.z) * inv.z, t2z = ((double)hi[2] - o.z) * inv.z;
+    double tn = fmax(fmax(fmin(t1x, t2x), fmin(t1y, t2y)), fmax(fmin(t1z, t2z), t_min));
+    double tf = fmin(fmin(fmax(t1x, t2x), fmax(t1y, t2y)), fmin(fmax(t1z, t2z), t_max));
+    t_near = tn;
+    return tn <= tf;
+}
+PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint32_t gid, Closest& best) {
+    const PrimRef pr = sc.prims[gid];
+    if ((pr.kind & 0xFFu) == PRIM_SPHERE) {
+        double t;
+        V3 c;
+        if (hit_sphere(sc.spheres[pr.index], r, t_min, t, c)) consider(best, t, gid);
+    } else {
+        double t, a, b;
+        if (hit_quad(sc.quads[pr.index], r, t_min, t, a, b)) consider(best, t, gid);
+    }
+}
+
+PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uint32_t* stk /* &stack[0][lane] */) {
+    Closest best{D_INF, HIT_NONE};
+    RayD r = wray;
+    V3 inv{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
+    int sp = 0;
+    uint32_t cur = sc.tlas_root;
+    for (;;) {
+        if ((cur & REF_TYPE_MASK) == REF_NODE) {
+            const BvhNode* nd = &sc.nodes[cur];
+            // 64-B node: four 16-B loads
+            const float4 q0 = ((const float4*)nd)[0], q1 = ((const float4*)nd)[1], q2 = ((const float4*)nd)[2];
+            const uint4 q3 = ((const uint4*)nd)[3];
+            const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+            const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+            double tn0, tn1;
+            bool h0 = slab(lo0, hi0, r.o, inv, t_min, best.t, tn0);
+            bool h1 = slab(lo1, hi1, r.o, inv, t_min, best.t, tn1);
+            uint32_t c0 = q3.x, c1 = q3.y;
+            if (h0 && h1) {
+                if (tn1 < tn0) {
+                    uint32_t tmp = c0;
+                    c0 = c1;
+                    c1 = tmp;
+                }
+                if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = c1;
+                cur = c0;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
+            const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
+            for (uint32_t i = first; i < first + count; ++i) {
+                double t, u, v;
+                if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
+            }
+        } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
+            const Entry e = sc.entries[cur & 0x3FFFFFFFu];
+            RayD lr = wray;
+            if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], wray);
+            if (e.kind == ENTRY_MESH) {
+                r = lr;
+                inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
+                if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = REF_LEAVE_INSTANCE;
+                cur = e.blas_root;
+                continue;
+            }
+            const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
+            for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+        } else if (cur == REF_LEAVE_INSTANCE) {
+            r = wray;
+            inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
+        }
+        if (sp == 0) break;
+        cur = stk[(--sp) * BLOCK];
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t seed) {
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_slots; s += gridDim.x * BLOCK) {
+        const uint32_t pixel = s % pool.n_pixels, sub = s / pool.n_pixels;
+        const uint32_t sample = pool.spp_begin + sub;
+        pool.ax[s] = 0.0; pool.ay[s] = 0.0; pool.az[s] = 0.0;
+        pool.rx[s] = 0.0; pool.ry[s] = 0.0; pool.rz[s] = 0.0;
+        pool.tx[s] = 1.0; pool.ty[s] = 1.0; pool.tz[s] = 1.0;
+        pool.sample[s] = sample;
+        pool.hit_prim[s] = HIT_NONE;
+        pool.hit_t[s] = D_INF;
+        if (sample >= pool.spp_end) {
+            pool.bounce[s] = SLOT_DEAD;
+            pool.draw[s] = 0;
+            continue;
+        }
+        Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, 0u};
+        RayD r = generate_ray(cam, pixel / cam.width, pixel % cam.width, rng);
+        pool.ox[s] = r.o.x; pool.oy[s] = r.o.y; pool.oz[s] = r.o.z;
+        pool.dx[s] = r.d.x; pool.dy[s] = r.d.y; pool.dz[s] = r.d.z;
+        pool.time[s] = r.time;
+        pool.bounce[s] = 0;
+        pool.draw[s] = rng.draw;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
+    __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
+    unsigned long long nseg = 0;
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_slots; s += gridDim.x * BLOCK) {
+        if (pool.bounce[s] == SLOT_DEAD) continue;
+        RayD r{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
+        Closest c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
+        pool.hit_t[s] = c.t;
+        pool.hit_prim[s] = c.id;
+        ++nseg;
+    }
+    if (nseg) atomicAdd(&cnt->segments, nseg);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
+    unsigned long long n_done = 0, n_died = 0;
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_slots; s += gridDim.x * BLOCK) {
+        uint32_t bounce = pool.bounce[s];
+        if (bounce == SLOT_DEAD) continue;
+        const uint32_t pixel = s % pool.n_pixels;
+        RayD ray{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
+        V3 thr{pool.tx[s], pool.ty[s], pool.tz[s]};
+        V3 rad{pool.rx[s], pool.ry[s], pool.rz[s]};
+        Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, pool.sample[s], pool.draw[s]};
+        const uint32_t gid = pool.hit_prim[s];
+        bool finished = false;
+        HitD hit;
+        if (gid == HIT_NONE || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
+            rad = rad + thr * sample_environment(sc, cam, ray.d);   // camera.rs:180-183
+            finished = true;
+        } else {
+            const MatD& m = sc.mats[hit.mat];
+            // camera.rs:186-187 — added for every material (zero unless emissive) so that a
+            // non-finite throughput poisons the sample exactly as it does in the reference
+            V3 emission = m.kind == MAT_LIGHT ? tex_rgb(sc, m.color_tex, hit.u, hit.v, hit.point) : V3{0.0, 0.0, 0.0};
+            rad = rad + thr * emission;
+            if (bounce > 5) {                                        // russian roulette :190-196
+                double p = clampd(luminance(thr), 0.01, 1.0);
+                if (rng_f64(rng) > p) finished = true;
+                else thr = thr / p;
+            }
+            if (!finished) {
+                const double p_light = sc.n_lights == 0 ? 0.0 : 0.5;   // :199-200
+                const double p_bsdf = 1.0 - p_light;
+                const V3 wo = -ray.d;
+                double rsel = rng_f64(rng);
+                V3 dir;
+                bool ok = true;
+                if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
+                else ok = mat_sample(sc, m, hit, wo, rng, cam.two_pi_scale, dir);
+                if (!ok) {
+                    finished = true;                                 // :209-211
+                } else {
+                    double bsdf_pdf;
+                    V3 brdf;
+                    mat_pdf_eval(sc, m, hit, wo, dir, bsdf_pdf, brdf);
+                    double light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
+                    double pdf = p_bsdf * bsdf_pdf + p_light * light_pdf;
+                    V3 attenuation = brdf / pdf;
+                    double e = 1e-3 * signum(dot(dir, hit.gn));      // :217-222
+                    ray = make_ray(hit.point + e * hit.gn, dir, ray.time);
+                    thr = thr * attenuation;
+                    ++bounce;
+                    if (bounce >= cam.max_depth) finished = true;    // loop bound :177
+                }
+            }
+        }
+        if (finished) {
+            pool.ax[s] += rad.x; pool.ay[s] += rad.y; pool.az[s] += rad.z;   // camera.rs:107
+            ++n_done;
+            const uint32_t next = pool.sample[s] + pool.k;
+            if (next < pool.spp_end) {
+                rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, next, 0u};
+                ray = generate_ray(cam, pixel / cam.width, pixel % cam.width, rng);
+                thr = V3{1.0, 1.0, 1.0};
+                rad = V3{0.0, 0.0, 0.0};
+                bounce = 0;
+                pool.sample[s] = next;
+            } else {
+                bounce = SLOT_DEAD;
+                ++n_died;
+            }
+        }
+        pool.bounce[s] = bounce;
+        if (bounce != SLOT_DEAD) {
+            pool.ox[s] = ray.o.x; pool.oy[s] = ray.o.y; pool.oz[s] = ray.o.z;
+            pool.dx[s] = ray.d.x; pool.dy[s] = ray.d.y; pool.dz[s] = ray.d.z;
+            pool.time[s] = ray.time;
+            pool.tx[s] = thr.x; pool.ty[s] = thr.y; pool.tz[s] = thr.z;
+            pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z;
+            pool.draw[s] = rng.draw;
+        }
+    }
+    if (n_done) atomicAdd(&cnt->samples, n_done);
+    if (n_died) atomicSub(&cnt->alive, n_died);
+}
+
+// accum[p*3+c] += sum over the k slots of pixel p, in slot order (k == 1: the exact
+// sample-order sum the reference computes at camera.rs:106-108)
+__global__ __launch_bounds__(BLOCK) void k_resolve(PoolD pool, double* accum) {
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < pool.n_pixels; p += gridDim.x * BLOCK) {
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (uint32_t j = 0; j < pool.k; ++j) {
+            const uint32_t s = j * pool.n_pixels + p;
+            if (j == 0) { sx = pool.ax[s]; sy = pool.ay[s]; sz = pool.az[s]; }
+            else { sx += pool.ax[s]; sy += pool.ay[s]; sz += pool.az[s]; }
+        }
+        accum[3 * (size_t)p] += sx;
+        accum[3 * (size_t)p + 1] += sy;
+        accum[3 * (size_t)p + 2] += sz;
+    }
+}
+
+// camera.rs:109-114,128-130: mean, sqrt gamma, clamp, truncate to u8
+__global__ __launch_bounds__(BLOCK) void k_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        double c = accum[i] * scale;
+        double g = sqrt(fmax(c, 0.0));
+        double q = clampd(g, 0.0, 0.999) * 256.0;
+        rgb8[i] = (q != q) ? (uint8_t)0 : (uint8_t)q;
+    }
+}
+
+// Debug/parity probe: closest hit + reconstructed HitInfo for a batch of arbitrary rays.
+// out[15*i..] = {hit, t, prim_id, u, v, front, p.xyz, gn.xyz, sn.xyz}
+__global__ __launch_bounds__(BLOCK) void k_probe(SceneD sc, const double* rays /* o.xyz d.xyz time */, uint32_t n, double* out) {
+    __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double* q = rays + 7 * (size_t)i;
+        RayD r = make_ray(V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, q[6]);
+        Closest c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);
+        double* o = out + 15 * (size_t)i;
+        for (int j = 0; j < 15; ++j) o[j] = 0.0;
+        HitD h;
+        if (c.id != HIT_NONE && reconstruct_hit(sc, r, c.id, 1e-3, h)) {
+            o[0] = 1.0; o[1] = c.t; o[2] = (double)c.id; o[3] = h.u; o[4] = h.v; o[5] = h.front ? 1.0 : 0.0;
+            o[6] = h.point.x; o[7] = h.point.y; o[8] = h.point.z;
+            o[9] = h.gn.x; o[10] = h.gn.y; o[11] = h.gn.z;
+            o[12] = h.sn.x; o[13] = h.sn.y; o[14] = h.sn.z;
+        }
+    }
+}
+
+// Elementwise probes of the device arithmetic (sqrt/div/fma-free mul-add, libm calls, RNG)
+// so that tests can compare them with the host bit for bit / ulp for ulp.
+__global__ void k_math_probe(int which, const double* in, uint32_t n, double* out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double a = in[2 * (size_t)i], b = in[2 * (size_t)i + 1], r = 0.0;
+        switch (which) {
+        case 0: r = sqrt(a); break;
+        case 1: r = a / b; break;
+        case 2: r = a * b + a; break;      // must NOT be fused
+        case 3: r = sin(a); break;
+        case 4: r = cos(a); break;
+        case 5: r = acos(a); break;
+        case 6: r = atan2(a, b); break;
+        case 7: r = pow(a, b); break;
+        case 8: r = log2(a); break;
+        case 9: {
+            Rng g{(uint32_t)(long long)a, 0u, (uint32_t)(long long)b, 7u, (uint32_t)i};
+            r = rng_f64(g);
+            break;
+        }
+        }
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------- launchers
+static inline dim3 grid_for(uint32_t n, int max_blocks) {
+    uint32_t b = (n + BLOCK - 1) / BLOCK;
+    if (b > (uint32_t)max_blocks) b = (uint32_t)max_blocks;
+    if (b == 0) b = 1;
+    return dim3(b);
+}
+void launch_init(const CamD& cam, const PoolD& pool, uint64_t seed, int max_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_init, grid_for(pool.n_slots, max_blocks), dim3(BLOCK), 0, st, cam, pool, seed);
+}
+void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_extend, grid_for(pool.n_slots, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+}
+void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(k_shade, grid_for(pool.n_slots, max_blocks), dim3(BLOCK), 0, st, sc, cam, pool, cnt, seed);
+}
+void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);
+}
+void launch_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8, hipStream_t st) {
+    hipLaunchKernelGGL(k_quantise, grid_for(n, 4096), dim3(BLOCK), 0, st, accum, n, scale, rgb8);
+}
+void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, sc, rays, n, out);
+}
+void launch_math_probe(int which, const double* in, uint32_t n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_math_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, which, in, n, out);
+}
+int kernel_occupancy_blocks(int which) {
+    int nb = 0;
+    const void* f = which == 0 ? (const void*)k_extend : (const void*)k_shade;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+}  // namespace pt

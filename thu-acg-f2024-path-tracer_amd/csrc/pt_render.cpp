@@ -1,0 +1,381 @@
+// Context management and the wavefront render loop (host side of Camera::render,
+// camera.rs:79-126): size the path pool, launch init -> {extend, shade}* -> resolve on one HIP
+// stream, poll the live-slot counter every few iterations, report per-kernel HIP-event times.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/pt_amd.h"
+#include "pt_kernels.h"
+#include "pt_scene.h"
+
+using namespace pt;
+using namespace pt::host;
+
+extern "C" const char* pt_last_error(void) { return pt::last_error(); }
+extern "C" int pt_set_error_message(const char* msg) { return set_error(msg); }
+
+extern "C" int pt_ctx_create(int device, pt_ctx** out) {
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_error("pt_ctx_create: no HIP device available — this library has no CPU fallback");
+    if (device < 0 || device >= n) return set_error("pt_ctx_create: device index out of range");
+    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return -1;
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return -1;
+    pt_ctx* c = new pt_ctx();
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        delete c;
+        return -1;
+    }
+    *out = c;
+    return 0;
+}
+extern "C" void pt_ctx_destroy(pt_ctx* c) {
+    if (!c) return;
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int pt_device_name(pt_ctx* c, char* buf, uint32_t n) {
+    if (!c || !buf || n == 0) return set_error("pt_device_name: bad arguments");
+    strncpy(buf, c->name.c_str(), n - 1);
+    buf[n - 1] = 0;
+    return 0;
+}
+extern "C" pt_scene* pt_scene_create(pt_ctx* c) {
+    if (!c) {
+        set_error("pt_scene_create: null context");
+        return nullptr;
+    }
+    pt_scene* s = new pt_scene();
+    s->ctx = c;
+    return s;
+}
+extern "C" void pt_scene_destroy(pt_scene* s) { delete s; }
+extern "C" pt_ctx* pt_scene_ctx(pt_scene* s) { return s ? s->ctx : nullptr; }
+extern "C" int pt_find_registered_image(pt_scene* s, const char* name) {
+    auto it = s->images.find(name);
+    return it == s->images.end() ? -1 : it->second;
+}
+
+// Camera::init camera.rs:51-77 (host, once per render)
+namespace {
+struct CamDerived {
+    D3 forward, right, up, center, pixel00, pixel_du, pixel_dv;
+    uint32_t height;
+};
+int derive_camera(const pt_camera* c, CamDerived& d) {
+    if (c->image_width == 0 || !(c->aspect_ratio > 0.0)) return set_error("camera: image_width and aspect_ratio must be positive");
+    d.height = (uint32_t)((double)c->image_width / c->aspect_ratio);
+    if (d.height == 0) return set_error("camera: image height is zero");
+    d.center = d3(c->look_from);
+    double theta = c->vfov * (PI / 180.0);   // f64::to_radians
+    double h = std::tan(theta / 2.0);
+    double viewport_height = 2.0 * h * c->focal_length;
+    double viewport_width = viewport_height * ((double)c->image_width / (double)d.height);
+    d.forward = normalize(d3(c->look_from) - d3(c->look_at));
+    d.right = normalize(cross(d3(c->vup), d.forward));
+    d.up = cross(d.forward, d.right);
+    D3 viewport_u = d.right * viewport_width;
+    D3 viewport_v = d.up * -viewport_height;
+    d.pixel_du = viewport_u / (double)c->image_width;
+    d.pixel_dv = viewport_v / (double)d.height;
+    D3 upperleft = d.center - (d.forward * c->focal_length) - (viewport_u / 2.0) - (viewport_v / 2.0);
+    d.pixel00 = upperleft + (d.pixel_du + d.pixel_dv) * 0.5;
+    return 0;
+}
+}  // namespace
+extern "C" int pt_camera_init(const pt_camera* c, double out[18], uint32_t* image_height) {
+    CamDerived d;
+    if (derive_camera(c, d) != 0) return -1;
+    const D3 v[6] = {d.forward, d.right, d.up, d.pixel00, d.pixel_du, d.pixel_dv};
+    for (int i = 0; i < 6; ++i) st3(out + 3 * i, v[i]);
+    *image_height = d.height;
+    return 0;
+}
+
+namespace {
+struct EventTimer {   // per-launch HIP-event timing, drained at the polling syncs
+    struct Pending {
+        hipEvent_t a, b;
+        int kind;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_list;
+    double ms[3] = {0, 0, 0};
+    uint64_t launches[3] = {0, 0, 0};
+    bool enabled = false;
+    hipEvent_t get() {
+        if (!free_list.empty()) {
+            hipEvent_t e = free_list.back();
+            free_list.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(int kind, hipStream_t st) {
+        ++launches[kind];
+        if (!enabled) return;
+        Pending p{get(), get(), kind};
+        (void)hipEventRecord(p.a, st);
+        pending.push_back(p);
+    }
+    void end(hipStream_t st) {
+        if (!enabled) return;
+        (void)hipEventRecord(pending.back().b, st);
+    }
+    void drain() {   // call after a stream sync
+        for (auto& p : pending) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) ms[p.kind] += t;
+            free_list.push_back(p.a);
+            free_list.push_back(p.b);
+        }
+        pending.clear();
+    }
+    ~EventTimer() {
+        drain();
+        for (auto e : free_list) (void)hipEventDestroy(e);
+    }
+};
+}  // namespace
+
+extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, double* accum,
+                         const pt_render_opts* opts_in, pt_render_stats* stats) {
+    if (!s || !s->built) return set_error("pt_render: world not built (call pt_world_build)");
+    if (!accum) return set_error("pt_render: null accumulator");
+    if (spp_end < spp_begin) return set_error("pt_render: spp_end < spp_begin");
+    pt_render_opts opts;
+    memset(&opts, 0, sizeof opts);
+    if (opts_in) opts = *opts_in;
+    pt_ctx* ctx = s->ctx;
+    if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return -1;
+    hipStream_t st = opts.stream ? (hipStream_t)opts.stream : ctx->stream;
+
+    CamDerived cd;
+    if (derive_camera(cam, cd) != 0) return -1;
+    CamD dc;
+    memset(&dc, 0, sizeof dc);
+    st3(dc.center, cd.center); st3(dc.pixel00, cd.pixel00); st3(dc.pixel_du, cd.pixel_du); st3(dc.pixel_dv, cd.pixel_dv);
+    double lens_radius = std::tan((cam->defocus_angle / 2.0) * (PI / 180.0)) * cam->focal_length;   // camera.rs:159
+    st3(dc.dof_right, cd.right * lens_radius);
+    st3(dc.dof_up, cd.up * lens_radius);
+    dc.blur_strength = cam->blur_strength;
+    for (int i = 0; i < 3; ++i) dc.env_color[i] = cam->env_color[i];
+    {   // rand 0.8.5 UniformFloat::new_inclusive(0, 2pi): scale = (high-low)/(1-eps), nudged down if needed
+        const double hi = 2.0 * PI, max_rand = 1.0 - 1.0 / 4503599627370496.0;
+        double scale = hi / max_rand;
+        while (!(scale * max_rand <= hi)) scale = std::nextafter(scale, 0.0);
+        dc.two_pi_scale = scale;
+    }
+    dc.width = cam->image_width;
+    dc.height = cd.height;
+    dc.max_depth = cam->max_depth;
+    dc.env_is_map = cam->env_is_map ? 1u : 0u;
+    dc.env_tex = cam->env_tex;
+    dc.n_lights = s->dev.view.n_lights;
+    if (dc.env_is_map) {
+        if (cam->env_tex < 0 || (size_t)cam->env_tex >= s->tex.size() || s->tex[cam->env_tex].d.kind != TEX_IMAGE)
+            return set_error("pt_render: env_tex must be an image texture of this scene");
+    }
+    const uint64_t n_pixels64 = (uint64_t)dc.width * dc.height;
+    if (n_pixels64 == 0 || n_pixels64 > 0x7FFFFFFFull) return set_error("pt_render: bad image size");
+    const uint32_t n_pixels = (uint32_t)n_pixels64;
+    const uint32_t spp = spp_end - spp_begin;
+
+    // pool sizing: k slots per pixel. Auto: enough resident paths to fill the machine several
+    // times over (occupancy + tail balance), capped by the sample count and by memory.
+    uint32_t k = opts.slots_per_pixel;
+    if (k == 0) {
+        const uint64_t target = (uint64_t)ctx->n_cus * 16384ull;   // ~4M paths on 256 CUs
+        k = (uint32_t)((target + n_pixels - 1) / n_pixels);
+        if (const char* e = getenv("PT_SLOTS_PER_PIXEL")) k = (uint32_t)atoi(e);
+    }
+    if (k > spp) k = spp;
+    if (k == 0) k = 1;
+    while ((uint64_t)k * n_pixels > 0x40000000ull && k > 1) --k;
+    const uint64_t n_slots64 = (uint64_t)k * n_pixels;
+    if (n_slots64 > 0x7FFFFFFFull) return set_error("pt_render: image too large for the path pool");
+    const uint32_t n_slots = (uint32_t)n_slots64;
+
+    // one allocation, carved into the SoA arrays (17 f64 + 4 u32 per slot)
+    const size_t n_al = ((size_t)n_slots + 63) & ~(size_t)63;
+    const size_t bytes = n_al * (17 * sizeof(double) + 4 * sizeof(uint32_t));
+    if (bytes > s->pool_bytes) {
+        if (s->pool_mem) (void)hipFree(s->pool_mem);
+        s->pool_mem = nullptr;
+        s->pool_bytes = 0;
+        if (!hip_ok(hipMalloc(&s->pool_mem, bytes), "hipMalloc(path pool)")) return -1;
+        s->pool_bytes = bytes;
+    }
+    if (!s->d_counters) {
+        if (!hip_ok(hipMalloc((void**)&s->d_counters, sizeof(CountersD)), "hipMalloc(counters)")) return -1;
+        if (!hip_ok(hipHostMalloc((void**)&s->h_counters, sizeof(CountersD), hipHostMallocDefault), "hipHostMalloc(counters)")) return -1;
+    }
+    PoolD pool;
+    memset(&pool, 0, sizeof pool);
+    {
+        double* d = (double*)s->pool_mem;
+        double** f64s[17] = {&pool.ox, &pool.oy, &pool.oz, &pool.dx, &pool.dy, &pool.dz, &pool.time, &pool.tx, &pool.ty,
+                             &pool.tz, &pool.rx, &pool.ry, &pool.rz, &pool.ax, &pool.ay, &pool.az, &pool.hit_t};
+        for (auto p : f64s) { *p = d; d += n_al; }
+        uint32_t* u = (uint32_t*)d;
+        uint32_t** u32s[4] = {&pool.hit_prim, &pool.sample, &pool.bounce, &pool.draw};
+        for (auto p : u32s) { *p = u; u += n_al; }
+    }
+    pool.n_slots = n_slots;
+    pool.n_pixels = n_pixels;
+    pool.k = k;
+    pool.spp_begin = spp_begin;
+    pool.spp_end = spp_end;
+
+    // accumulator on the device
+    double* d_accum = accum;
+    const size_t accum_bytes = (size_t)n_pixels * 3 * sizeof(double);
+    if (!opts.accum_on_device) {
+        if (!hip_ok(hipMalloc((void**)&d_accum, accum_bytes), "hipMalloc(accum)")) return -1;
+        if (!hip_ok(hipMemsetAsync(d_accum, 0, accum_bytes, st), "hipMemset(accum)")) return -1;
+    }
+
+    // persistent grids: resident blocks per CU x CUs
+    int mult = 1;
+    if (const char* e = getenv("PT_GRID_MULT")) mult = std::max(1, atoi(e));
+    const int blocks_extend = kernel_occupancy_blocks(0), blocks_shade = kernel_occupancy_blocks(1);
+    const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
+
+    CountersD init_cnt;
+    memset(&init_cnt, 0, sizeof init_cnt);
+    init_cnt.alive = spp == 0 ? 0 : n_slots;   // k <= spp, so every slot has at least one sample
+    if (!hip_ok(hipMemcpyAsync(s->d_counters, &init_cnt, sizeof init_cnt, hipMemcpyHostToDevice, st), "hipMemcpy(counters)")) return -1;
+
+    EventTimer timer;
+    timer.enabled = opts.profile != 0;
+    auto t0 = std::chrono::steady_clock::now();
+    (void)hipStreamSynchronize(st);
+    t0 = std::chrono::steady_clock::now();
+
+    timer.begin(2, st);
+    launch_init(dc, pool, seed, grid_shade, st);
+    timer.end(st);
+    uint64_t iterations = 0;
+    const uint64_t per_slot = (spp + k - 1) / k;
+    const uint64_t max_iterations = per_slot * (uint64_t)std::max(1u, dc.max_depth) + 4;
+    uint32_t poll_every = 8;
+    bool alive = spp != 0 && dc.max_depth != 0;
+    if (spp != 0 && dc.max_depth == 0) {
+        // max_depth = 0: trace() returns zero radiance for every sample (camera.rs:177); nothing to launch
+        alive = false;
+    }
+    while (alive) {
+        for (uint32_t i = 0; i < poll_every; ++i) {
+            timer.begin(0, st);
+            launch_extend(s->dev.view, pool, s->d_counters, grid_extend, st);
+            timer.end(st);
+            timer.begin(1, st);
+            launch_shade(s->dev.view, dc, pool, s->d_counters, seed, grid_shade, st);
+            timer.end(st);
+            ++iterations;
+        }
+        if (!hip_ok(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(CountersD), hipMemcpyDeviceToHost, st), "hipMemcpy(counters)")) return -1;
+        if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(render)")) return -1;
+        timer.drain();
+        alive = s->h_counters->alive != 0;
+        if (iterations > max_iterations) return set_error("pt_render: iteration bound exceeded (internal error)");
+        if (poll_every < 64) poll_every *= 2;
+    }
+    timer.begin(2, st);
+    launch_resolve(pool, d_accum, ctx->n_cus * 8, st);
+    timer.end(st);
+    if (!hip_ok(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(CountersD), hipMemcpyDeviceToHost, st), "hipMemcpy(counters)")) return -1;
+    if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(resolve)")) return -1;
+    timer.drain();
+    auto t1 = std::chrono::steady_clock::now();
+    if (!hip_ok(hipGetLastError(), "kernel launch")) return -1;
+
+    if (!opts.accum_on_device) {
+        std::vector<double> tmp((size_t)n_pixels * 3);
+        bool ok = hip_ok(hipMemcpy(tmp.data(), d_accum, accum_bytes, hipMemcpyDeviceToHost), "hipMemcpy(accum)");
+        (void)hipFree(d_accum);
+        if (!ok) return -1;
+        for (size_t i = 0; i < tmp.size(); ++i) accum[i] += tmp[i];
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->samples = s->h_counters->samples;
+        stats->segments = s->h_counters->segments;
+        stats->iterations = iterations;
+        stats->n_slots = n_slots;
+        stats->slots_per_pixel = k;
+        stats->ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        stats->ms_extend = timer.ms[0];
+        stats->ms_shade = timer.ms[1];
+        stats->ms_other = timer.ms[2];
+        stats->launches_extend = timer.launches[0];
+        stats->launches_shade = timer.launches[1];
+        stats->blocks_extend = (uint32_t)grid_extend;
+        stats->blocks_shade = (uint32_t)grid_shade;
+    }
+    return 0;
+}
+
+extern "C" int pt_resolve_u8(pt_ctx* ctx, const double* accum, uint32_t n_pixels, uint32_t total_spp, uint8_t* rgb8) {
+    if (!ctx) return set_error("pt_resolve_u8: null context");
+    if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return -1;
+    const uint32_t n = n_pixels * 3;
+    double* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    bool ok = hip_ok(hipMalloc((void**)&d_in, (size_t)n * sizeof(double)), "hipMalloc") && hip_ok(hipMalloc((void**)&d_out, n), "hipMalloc") &&
+              hip_ok(hipMemcpyAsync(d_in, accum, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpy");
+    if (ok) {
+        launch_quantise(d_in, n, 1.0 / (double)total_spp, d_out, ctx->stream);   // pixel_sample_scale camera.rs:53
+        ok = hip_ok(hipMemcpyAsync(rgb8, d_out, n, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy") &&
+             hip_ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return ok ? 0 : -1;
+}
+
+extern "C" int pt_intersect(pt_scene* s, const double* rays, uint32_t n, double* out) {
+    if (!s || !s->built) return set_error("pt_intersect: world not built");
+    pt_ctx* ctx = s->ctx;
+    if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return -1;
+    double *d_r = nullptr, *d_o = nullptr;
+    bool ok = hip_ok(hipMalloc((void**)&d_r, (size_t)n * 7 * sizeof(double) + 8), "hipMalloc") &&
+              hip_ok(hipMalloc((void**)&d_o, (size_t)n * 15 * sizeof(double) + 8), "hipMalloc") &&
+              hip_ok(hipMemcpyAsync(d_r, rays, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpy");
+    if (ok) {
+        launch_probe(s->dev.view, d_r, n, d_o, ctx->stream);
+        ok = hip_ok(hipMemcpyAsync(out, d_o, (size_t)n * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy") &&
+             hip_ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
+    if (d_r) (void)hipFree(d_r);
+    if (d_o) (void)hipFree(d_o);
+    return ok ? 0 : -1;
+}
+
+extern "C" int pt_math_probe(pt_ctx* ctx, int which, const double* in, uint32_t n, double* out) {
+    if (!ctx) return set_error("pt_math_probe: null context");
+    if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return -1;
+    double *d_i = nullptr, *d_o = nullptr;
+    bool ok = hip_ok(hipMalloc((void**)&d_i, (size_t)n * 2 * sizeof(double) + 8), "hipMalloc") &&
+              hip_ok(hipMalloc((void**)&d_o, (size_t)n * sizeof(double) + 8), "hipMalloc") &&
+              hip_ok(hipMemcpyAsync(d_i, in, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpy");
+    if (ok) {
+        launch_math_probe(which, d_i, n, d_o, ctx->stream);
+        ok = hip_ok(hipMemcpyAsync(out, d_o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy") &&
+             hip_ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
+    if (d_i) (void)hipFree(d_i);
+    if (d_o) (void)hipFree(d_o);
+    return ok ? 0 : -1;
+}

@@ -1,0 +1,572 @@
+// Scene builder + flattener + BVH builder (host). See pt_scene.h.
+#include "pt_scene.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+
+#include "../../include/pt_amd.h"
+
+using namespace pt;
+using namespace pt::host;
+
+namespace pt {
+static thread_local std::string g_error;
+int set_error(const std::string& msg) {
+    g_error = msg;
+    return -1;
+}
+const char* last_error() { return g_error.c_str(); }
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+void DeviceBuffers::release() {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    view = SceneD{};
+}
+}  // namespace pt
+
+pt_scene::~pt_scene() {
+    dev.release();
+    if (pool_mem) (void)hipFree(pool_mem);
+    if (d_counters) (void)hipFree(d_counters);
+    if (h_counters) (void)hipHostFree(h_counters);
+}
+
+#define TEX_RGB_OK(s, t) ((t) >= 0 && (size_t)(t) < (s)->tex.size() && (s)->tex[t].is_rgb)
+#define TEX_F_OK(s, t) ((t) >= 0 && (size_t)(t) < (s)->tex.size() && !(s)->tex[t].is_rgb)
+#define MAT_OK(s, m) ((m) >= 0 && (size_t)(m) < (s)->mats.size())
+#define OBJ_OK(s, o) ((o) >= 0 && (size_t)(o) < (s)->objs.size())
+
+static int push_tex(pt_scene* s, HostTex&& t) {
+    s->tex.push_back(std::move(t));
+    s->built = false;
+    return (int)s->tex.size() - 1;
+}
+extern "C" int pt_tex_solid_rgb(pt_scene* s, double r, double g, double b) {
+    HostTex t;
+    t.d.kind = TEX_SOLID_RGB;
+    t.d.v[0] = r; t.d.v[1] = g; t.d.v[2] = b;
+    t.is_rgb = true;
+    return push_tex(s, std::move(t));
+}
+extern "C" int pt_tex_solid_f(pt_scene* s, double v) {
+    HostTex t;
+    t.d.kind = TEX_SOLID_F;
+    t.d.v[0] = v;
+    return push_tex(s, std::move(t));
+}
+extern "C" int pt_tex_checker(pt_scene* s, double scale, int t1, int t2) {
+    if (!((TEX_RGB_OK(s, t1) && TEX_RGB_OK(s, t2)) || (TEX_F_OK(s, t1) && TEX_F_OK(s, t2))))
+        return set_error("pt_tex_checker: both child textures must exist and have the same value type");
+    HostTex t;
+    t.d.kind = TEX_CHECKER;
+    t.d.t1 = (uint32_t)t1; t.d.t2 = (uint32_t)t2;
+    t.d.inv_scale = 1.0 / scale;   // scale.recip() texture.rs:36
+    t.is_rgb = s->tex[t1].is_rgb;
+    return push_tex(s, std::move(t));
+}
+extern "C" int pt_tex_image_rgb8(pt_scene* s, uint32_t w, uint32_t h, const uint8_t* rgb) {
+    if (!rgb && w != 0 && h != 0) return set_error("pt_tex_image_rgb8: null pixels");
+    HostTex t;
+    t.d.kind = TEX_IMAGE;
+    t.d.w = w; t.d.h = h;
+    t.image.assign(rgb, rgb + (size_t)w * h * 3);
+    t.is_rgb = true;
+    return push_tex(s, std::move(t));
+}
+extern "C" int pt_register_image(pt_scene* s, const char* name, uint32_t w, uint32_t h, const uint8_t* rgb) {
+    int t = pt_tex_image_rgb8(s, w, h, rgb);
+    if (t < 0) return -1;
+    s->images[name] = t;
+    return 0;
+}
+
+static int push_mat(pt_scene* s, const MatD& m) {
+    s->mats.push_back(m);
+    s->built = false;
+    return (int)s->mats.size() - 1;
+}
+static MatD blank_mat(uint32_t kind) {
+    MatD m;
+    memset(&m, 0, sizeof m);
+    m.kind = kind;
+    m.color_tex = m.rough_tex = m.nmap_tex = -1;
+    return m;
+}
+extern "C" int pt_mat_diffuse(pt_scene* s, int color_tex, int nmap) {
+    if (!TEX_RGB_OK(s, color_tex)) return set_error("pt_mat_diffuse: bad colour texture");
+    MatD m = blank_mat(MAT_DIFFUSE);
+    m.color_tex = color_tex;
+    if (nmap >= 0) {
+        if (!TEX_RGB_OK(s, nmap) || s->tex[nmap].d.kind != TEX_IMAGE) return set_error("pt_mat_diffuse: normal map must be an image texture");
+        m.nmap_tex = nmap;
+    }
+    return push_mat(s, m);
+}
+extern "C" int pt_mat_metal(pt_scene* s, int color_tex, int rough_tex) {
+    if (!TEX_RGB_OK(s, color_tex) || !TEX_F_OK(s, rough_tex)) return set_error("pt_mat_metal: bad texture handle");
+    MatD m = blank_mat(MAT_METAL);
+    m.color_tex = color_tex;
+    m.rough_tex = rough_tex;
+    return push_mat(s, m);
+}
+extern "C" int pt_mat_glass(pt_scene* s, int color_tex, int rough_tex, double, double ior) {
+    if (!TEX_RGB_OK(s, color_tex) || !TEX_F_OK(s, rough_tex)) return set_error("pt_mat_glass: bad texture handle");
+    MatD m = blank_mat(MAT_GLASS);
+    m.color_tex = color_tex;
+    m.rough_tex = rough_tex;
+    m.ior = ior;
+    return push_mat(s, m);
+}
+extern "C" int pt_mat_principled(pt_scene* s, int color_tex, const double p[11]) {
+    if (!TEX_RGB_OK(s, color_tex)) return set_error("pt_mat_principled: bad colour texture");
+    MatD m = blank_mat(MAT_PRINCIPLED);
+    m.color_tex = color_tex;
+    for (int i = 0; i < 11; ++i) m.p[i] = p[i];
+    m.ior = p[5];
+    const double metallic = p[0], spec_trans = p[6], clearcoat = p[9], gloss = p[10];
+    m.lobe_w[0] = (1.0 - metallic) * (1.0 - spec_trans);   // principled.rs:79-85
+    m.lobe_w[1] = 1.0 - spec_trans * (1.0 - metallic);
+    m.lobe_w[2] = spec_trans * (1.0 - metallic);
+    m.lobe_w[3] = 0.25 * clearcoat;
+    double inv_total = 1.0 / (m.lobe_w[0] + m.lobe_w[1] + m.lobe_w[2] + m.lobe_w[3]);   // :87-100
+    for (int i = 0; i < 4; ++i) m.lobe_p[i] = m.lobe_w[i] * inv_total;
+    m.alpha_g = (1.0 - gloss) * 0.1 + gloss * 0.001;       // :75-77
+    return push_mat(s, m);
+}
+extern "C" int pt_mat_light(pt_scene* s, int tex) {
+    if (!TEX_RGB_OK(s, tex)) return set_error("pt_mat_light: bad emission texture");
+    MatD m = blank_mat(MAT_LIGHT);
+    m.color_tex = tex;
+    return push_mat(s, m);
+}
+
+static int push_obj(pt_scene* s, HostObj&& o) {
+    s->objs.push_back(std::move(o));
+    s->built = false;
+    return (int)s->objs.size() - 1;
+}
+static QuadD make_quad(D3 q, D3 u, D3 v) {   // Quad::new quad.rs:17-36
+    QuadD r;
+    D3 n = cross(u, v);
+    D3 normal = normalize(n);
+    st3(r.q, q); st3(r.u, u); st3(r.v, v);
+    st3(r.n, normal);
+    r.d = dot(normal, q);
+    st3(r.w, n / dot(n, n));
+    return r;
+}
+extern "C" int pt_sphere(pt_scene* s, double radius, const double p1[3], const double p2[3], int mat) {
+    if (!MAT_OK(s, mat)) return set_error("pt_sphere: bad material");
+    HostObj o;
+    o.kind = OBJ_SPHERE;
+    o.mat = mat;
+    o.sphere.r = std::fmax(radius, 0.0);   // sphere.rs:26
+    for (int i = 0; i < 3; ++i) { o.sphere.p1[i] = p1[i]; o.sphere.p2[i] = p2[i]; }
+    return push_obj(s, std::move(o));
+}
+extern "C" int pt_quad(pt_scene* s, const double q[3], const double u[3], const double v[3], int mat) {
+    if (!MAT_OK(s, mat)) return set_error("pt_quad: bad material");
+    HostObj o;
+    o.kind = OBJ_QUAD;
+    o.mat = mat;
+    o.quads.push_back(make_quad(d3(q), d3(u), d3(v)));
+    return push_obj(s, std::move(o));
+}
+extern "C" int pt_cuboid(pt_scene* s, const double a[3], const double b[3], int mat) {   // cuboid.rs:11-58
+    if (!MAT_OK(s, mat)) return set_error("pt_cuboid: bad material");
+    HostObj o;
+    o.kind = OBJ_CUBOID;
+    o.mat = mat;
+    D3 mn = vmin(d3(a), d3(b)), mx = vmax(d3(a), d3(b));
+    D3 dx{mx.x - mn.x, 0.0, 0.0}, dy{0.0, mx.y - mn.y, 0.0}, dz{0.0, 0.0, mx.z - mn.z};
+    o.quads.push_back(make_quad(D3{mn.x, mn.y, mx.z}, dx, dy));    // front
+    o.quads.push_back(make_quad(D3{mx.x, mn.y, mx.z}, -dz, dy));   // right
+    o.quads.push_back(make_quad(D3{mx.x, mn.y, mn.z}, -dx, dy));   // back
+    o.quads.push_back(make_quad(D3{mn.x, mn.y, mn.z}, dz, dy));    // left
+    o.quads.push_back(make_quad(D3{mn.x, mx.y, mx.z}, dx, -dz));   // top
+    o.quads.push_back(make_quad(D3{mn.x, mn.y, mn.z}, dx, dz));    // bottom
+    return push_obj(s, std::move(o));
+}
+extern "C" int pt_mesh(pt_scene* s, double scale, uint32_t n_pos, const float* pos, uint32_t n_idx, const uint32_t* idx,
+                       uint32_t n_nrm, const float* nrm, uint32_t n_uv, const float* uv, int mat) {   // mesh.rs:149-197
+    if (!MAT_OK(s, mat)) return set_error("pt_mesh: bad material");
+    if (n_idx % 3 != 0) return set_error("pt_mesh: index count must be a multiple of 3");
+    if (n_idx / 3 > 0x07FFFFFFu) return set_error("pt_mesh: too many triangles");
+    for (uint32_t i = 0; i < n_idx; ++i) {
+        if (idx[i] >= n_pos) return set_error("pt_mesh: position index out of range");
+        if (n_nrm && idx[i] >= n_nrm) return set_error("pt_mesh: normal index out of range");
+        if (n_uv && idx[i] >= n_uv) return set_error("pt_mesh: texcoord index out of range");
+    }
+    HostObj o;
+    o.kind = OBJ_MESH;
+    o.mat = mat;
+    o.has_normals = n_nrm != 0;
+    o.has_uvs = n_uv != 0;
+    auto vertex = [&](uint32_t i) { return D3{(double)pos[3 * i], (double)pos[3 * i + 1], (double)pos[3 * i + 2]} * scale; };
+    o.tris.resize(n_idx / 3);
+    if (o.has_normals || o.has_uvs) o.tri_attr.resize(n_idx / 3);
+    for (uint32_t f = 0; f < n_idx / 3; ++f) {
+        const uint32_t ii[3] = {idx[3 * f], idx[3 * f + 1], idx[3 * f + 2]};
+        st3(o.tris[f].v0, vertex(ii[0]));
+        st3(o.tris[f].v1, vertex(ii[1]));
+        st3(o.tris[f].v2, vertex(ii[2]));
+        if (!o.tri_attr.empty()) {
+            TriAttr& a = o.tri_attr[f];
+            memset(&a, 0, sizeof a);
+            for (int k = 0; k < 3; ++k) {
+                if (o.has_normals) for (int c = 0; c < 3; ++c) a.n[k][c] = (double)nrm[3 * ii[k] + c];
+                if (o.has_uvs) for (int c = 0; c < 2; ++c) a.uv[k][c] = (double)uv[2 * ii[k] + c];
+            }
+        }
+    }
+    return push_obj(s, std::move(o));
+}
+extern "C" int pt_instance(pt_scene* s, int obj, const double axis[3], double angle, const double tr[3]) {   // instance.rs:20-30
+    if (!OBJ_OK(s, obj)) return set_error("pt_instance: bad object handle");
+    if (s->objs[obj].kind == OBJ_INSTANCE) return set_error("pt_instance: nested instances are not supported");
+    if (s->objs[obj].used) return set_error("pt_instance: object is already placed (each object may be used once)");
+    s->objs[obj].used = true;
+    HostObj o;
+    o.kind = OBJ_INSTANCE;
+    o.child = obj;
+    // DQuat::from_axis_angle, DMat4::from_rotation_translation (glam 0.29 quat_to_axes)
+    double sn = std::sin(angle * 0.5), cs = std::cos(angle * 0.5);
+    D3 v = d3(axis) * sn;
+    double qx = v.x, qy = v.y, qz = v.z, qw = cs;
+    double x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+    double xx = qx * x2, xy = qx * y2, xz = qx * z2;
+    double yy = qy * y2, yz = qy * z2, zz = qz * z2;
+    double wx = qw * x2, wy = qw * y2, wz = qw * z2;
+    D3 c0{1.0 - (yy + zz), xy + wz, xz - wy};
+    D3 c1{xy - wz, 1.0 - (xx + zz), yz + wx};
+    D3 c2{xz + wy, yz - wx, 1.0 - (xx + yy)};
+    D3 t = d3(tr);
+    // analytic rigid inverse: R^T and -(R^T t)  
+    D3 i0{c0.x, c1.x, c2.x}, i1{c0.y, c1.y, c2.y}, i2{c0.z, c1.z, c2.z};
+    D3 it = -xform_vector(i0, i1, i2, t);
+    st3(o.xf.c0, c0); st3(o.xf.c1, c1); st3(o.xf.c2, c2); st3(o.xf.t, t);
+    st3(o.xf.i0, i0); st3(o.xf.i1, i1); st3(o.xf.i2, i2); st3(o.xf.it, it);
+    return push_obj(s, std::move(o));
+}
+static int place(pt_scene* s, int obj, std::vector<int>& list, const char* who) {
+    if (!OBJ_OK(s, obj)) return set_error(std::string(who) + ": bad object handle");
+    if (s->objs[obj].used) return set_error(std::string(who) + ": object is already placed (each object may be used once)");
+    s->objs[obj].used = true;
+    list.push_back(obj);
+    s->built = false;
+    return 0;
+}
+extern "C" int pt_world_add_object(pt_scene* s, int obj) { return place(s, obj, s->world_objects, "pt_world_add_object"); }
+extern "C" int pt_world_add_light(pt_scene* s, int obj) { return place(s, obj, s->world_lights, "pt_world_add_light"); }
+extern "C" uint32_t pt_world_prim_count(pt_scene* s) { return s->n_prims; }
+extern "C" int pt_world_build(pt_scene* s) { return scene_build(s); }
+
+// ----------------------------------------------------------------------------------------
+// BVH builder: top-down binned SAH (16 bins) over item boxes, depth-limited (falls back to
+// object-median splits when the remaining depth budget is tight) so that the traversal
+// kernel's LDS stack (TRAVERSAL_STACK levels) can never overflow. The reference's O(n^2)
+// full-sweep SAH (bvh.rs:54-120) is NOT reproduced: closest-hit results do not depend on the
+// tree, only on the canonical tie rule both sides share.
+// ----------------------------------------------------------------------------------------
+namespace {
+struct BuildItem {
+    Box box;
+    D3 c;
+    uint32_t ref_payload;   // original index
+};
+struct Builder {
+    std::vector<BvhNode>& nodes;
+    std::vector<BuildItem>& items;
+    int leaf_max, max_depth;
+    bool tri_leaves;                       // leaf = REF_TRIS range, else REF_ENTRY single
+    std::vector<uint32_t>* order;          // BLAS: output permutation (leaf order)
+    uint32_t leaf_base = 0;                // BLAS: index of this mesh's first triangle in the global array
+    int depth_reached = 0;
+
+    static float down(double v) {
+        float f = (float)v;
+        if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+        return f;
+    }
+    static float up(double v) {
+        float f = (float)v;
+        if ((double)f < v) f = std::nextafterf(f, INFINITY);
+        return f;
+    }
+    static void store_box(const Box& b, float* lo, float* hi) {
+        // pad, then round outward to f32: strictly conservative for the f64 slab test
+        double m = 1e-3;
+        const double v[6] = {b.lo.x, b.lo.y, b.lo.z, b.hi.x, b.hi.y, b.hi.z};
+        for (double x : v) m = std::fmax(m, std::fabs(x));
+        double pad = 1e-7 * m;
+        lo[0] = down(b.lo.x - pad); lo[1] = down(b.lo.y - pad); lo[2] = down(b.lo.z - pad);
+        hi[0] = up(b.hi.x + pad); hi[1] = up(b.hi.y + pad); hi[2] = up(b.hi.z + pad);
+    }
+    static double axis_of(D3 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
+
+    uint32_t make_leaf(size_t begin, size_t end) {
+        if (tri_leaves) {
+            uint32_t first = leaf_base + (uint32_t)order->size();
+            for (size_t i = begin; i < end; ++i) order->push_back(items[i].ref_payload);
+            return REF_TRIS | ((uint32_t)(end - begin - 1) << 27) | first;
+        }
+        return REF_ENTRY | items[begin].ref_payload;
+    }
+    // returns child reference; `out_box` = bounds of the subtree
+    uint32_t build(size_t begin, size_t end, int depth, Box& out_box) {
+        depth_reached = std::max(depth_reached, depth);
+        Box box, cbox;
+        for (size_t i = begin; i < end; ++i) { box.grow(items[i].box); cbox.grow(items[i].c); }
+        out_box = box;
+        const size_t n = end - begin;
+        if (n <= (size_t)leaf_max) return make_leaf(begin, end);
+        // depth budget: levels still needed with perfect median splits
+        int needed = 0;
+        for (size_t cap = (size_t)leaf_max; cap < n; cap *= 2) ++needed;
+        const bool force_median = needed >= max_depth - depth;
+        D3 ext = cbox.hi - cbox.lo;
+        int axis = ext.x >= ext.y && ext.x >= ext.z ? 0 : (ext.y >= ext.z ? 1 : 2);
+        size_t mid = begin + n / 2;
+        bool done = false;
+        if (!force_median) {
+            const int NB = 16;
+            double best_cost = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < 3; ++a) {
+                double lo = axis_of(cbox.lo, a), hi = axis_of(cbox.hi, a);
+                if (!(hi > lo)) continue;
+                Box bb[NB];
+                size_t bc[NB] = {0};
+                double k = (double)NB / (hi - lo);
+                for (size_t i = begin; i < end; ++i) {
+                    int b = (int)((axis_of(items[i].c, a) - lo) * k);
+                    b = std::min(std::max(b, 0), NB - 1);
+                    bb[b].grow(items[i].box);
+                    ++bc[b];
+                }
+                Box right_acc[NB];
+                size_t right_cnt[NB];
+                Box acc;
+                size_t cnt = 0;
+                for (int b = NB - 1; b > 0; --b) {
+                    acc.grow(bb[b]);
+                    cnt += bc[b];
+                    right_acc[b] = acc;
+                    right_cnt[b] = cnt;
+                }
+                acc = Box();
+                cnt = 0;
+                for (int b = 0; b < NB - 1; ++b) {
+                    acc.grow(bb[b]);
+                    cnt += bc[b];
+                    if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                    double cost = acc.half_area() * (double)cnt + right_acc[b + 1].half_area() * (double)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                double lo = axis_of(cbox.lo, best_axis), hi = axis_of(cbox.hi, best_axis);
+                double k = 16.0 / (hi - lo);
+                auto it = std::stable_partition(items.begin() + begin, items.begin() + end, [&](const BuildItem& it_) {
+                    int b = (int)((axis_of(it_.c, best_axis) - lo) * k);
+                    b = std::min(std::max(b, 0), 15);
+                    return b <= best_bin;
+                });
+                mid = (size_t)(it - items.begin());
+                done = mid > begin && mid < end;
+            }
+        }
+        if (!done) {
+            mid = begin + n / 2;
+            std::stable_sort(items.begin() + begin, items.begin() + end,
+                             [&](const BuildItem& a, const BuildItem& b) { return axis_of(a.c, axis) < axis_of(b.c, axis); });
+        }
+        uint32_t me = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        Box lb, rb;
+        uint32_t l = build(begin, mid, depth + 1, lb);
+        uint32_t r = build(mid, end, depth + 1, rb);
+        BvhNode& nd = nodes[me];
+        store_box(lb, nd.lo0, nd.hi0);
+        store_box(rb, nd.lo1, nd.hi1);
+        nd.child0 = l;
+        nd.child1 = r;
+        nd.pad0 = nd.pad1 = 0;
+        return REF_NODE | me;
+    }
+};
+
+template <class T>
+bool upload(DeviceBuffers& dev, const std::vector<T>& v, const T*& out) {
+    out = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void* p = nullptr;
+    if (!hip_ok(hipMalloc(&p, bytes), "hipMalloc(scene)")) return false;
+    dev.allocs.push_back(p);
+    if (!v.empty() && !hip_ok(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(scene)")) return false;
+    out = (const T*)p;
+    return true;
+}
+Box sphere_box(const SphereD& s) {
+    Box b;
+    D3 r{s.r, s.r, s.r};
+    b.grow(d3(s.p1) - r); b.grow(d3(s.p1) + r);
+    b.grow(d3(s.p2) - r); b.grow(d3(s.p2) + r);
+    return b;
+}
+Box quad_box(const QuadD& q) {
+    Box b;
+    D3 o = d3(q.q), u = d3(q.u), v = d3(q.v);
+    b.grow(o); b.grow(o + u); b.grow(o + v); b.grow(o + u + v);
+    return b;
+}
+Box xform_box(const Box& b, const InstD& m) {
+    Box r;
+    for (int i = 0; i < 8; ++i) {
+        D3 p{(i & 1) ? b.hi.x : b.lo.x, (i & 2) ? b.hi.y : b.lo.y, (i & 4) ? b.hi.z : b.lo.z};
+        r.grow(xform_point(d3(m.c0), d3(m.c1), d3(m.c2), d3(m.t), p));
+    }
+    return r;
+}
+}  // namespace
+
+int pt::scene_build(pt_scene* s) {
+    if (!s->ctx) return set_error("scene has no context");
+    if (!hip_ok(hipSetDevice(s->ctx->device), "hipSetDevice")) return -1;
+    s->dev.release();
+    s->built = false;
+
+    std::vector<BvhNode> nodes;
+    std::vector<Entry> entries;
+    std::vector<PrimRef> prims;
+    std::vector<SphereD> spheres;
+    std::vector<QuadD> quads;
+    std::vector<TriD> tris;
+    std::vector<TriAttr> tri_attr;
+    std::vector<uint32_t> tri_gid;
+    std::vector<InstD> insts;
+    std::vector<uint32_t> lights;
+    std::vector<BuildItem> tlas_items;
+    bool any_attr = false;
+    for (auto& o : s->objs) any_attr = any_attr || !o.tri_attr.empty();
+
+    // canonical global primitive ids: lights list first, then objects, insertion order
+    std::vector<int> order = s->world_lights;
+    order.insert(order.end(), s->world_objects.begin(), s->world_objects.end());
+    if (order.empty()) return set_error("pt_world_build: the world is empty");
+    int max_blas_depth = 0;
+    for (size_t wi = 0; wi < order.size(); ++wi) {
+        const HostObj* top = &s->objs[order[wi]];
+        int inst = -1;
+        const HostObj* o = top;
+        if (top->kind == OBJ_INSTANCE) {
+            inst = (int)insts.size();
+            insts.push_back(top->xf);
+            o = &s->objs[top->child];
+        }
+        const bool is_light = wi < s->world_lights.size();
+        if (is_light) {
+            if (inst >= 0 || (o->kind != OBJ_SPHERE && o->kind != OBJ_QUAD))
+                return set_error("pt_world_add_light: only un-instanced quads and spheres can be sampled as lights in this build");
+            lights.push_back((uint32_t)entries.size());
+        }
+        Entry e{};
+        e.first_prim = (uint32_t)prims.size();
+        e.inst = inst;
+        e.blas_root = REF_EMPTY;
+        Box local;
+        switch (o->kind) {
+        case OBJ_SPHERE:
+            e.kind = ENTRY_SPHERE;
+            prims.push_back(PrimRef{PRIM_SPHERE, (uint32_t)spheres.size(), (uint32_t)o->mat, inst});
+            spheres.push_back(o->sphere);
+            local = sphere_box(o->sphere);
+            break;
+        case OBJ_QUAD:
+        case OBJ_CUBOID:
+            e.kind = o->kind == OBJ_QUAD ? ENTRY_QUAD : ENTRY_CUBOID;
+            for (const QuadD& q : o->quads) {
+                prims.push_back(PrimRef{PRIM_QUAD, (uint32_t)quads.size(), (uint32_t)o->mat, inst});
+                quads.push_back(q);
+                local.grow(quad_box(q));
+            }
+            break;
+        case OBJ_MESH: {
+            e.kind = ENTRY_MESH;
+            if (o->tris.empty()) return set_error("pt_world_build: empty mesh");
+            std::vector<BuildItem> items(o->tris.size());
+            for (size_t i = 0; i < o->tris.size(); ++i) {
+                Box b;
+                b.grow(d3(o->tris[i].v0)); b.grow(d3(o->tris[i].v1)); b.grow(d3(o->tris[i].v2));
+                items[i] = BuildItem{b, b.centroid(), (uint32_t)i};
+                local.grow(b);
+            }
+            std::vector<uint32_t> perm;
+            const uint32_t tri_base = (uint32_t)tris.size();
+            if ((size_t)tri_base + o->tris.size() > 0x07FFFFFFu) return set_error("pt_world_build: too many triangles");
+            Builder bl{nodes, items, 4, MAX_BLAS_DEPTH, true, &perm, tri_base};
+            Box bb;
+            e.blas_root = bl.build(0, items.size(), 0, bb);
+            max_blas_depth = std::max(max_blas_depth, bl.depth_reached);
+            const uint32_t flags = PRIM_TRI | (o->has_normals ? PRIM_HAS_NORMALS : 0u) | (o->has_uvs ? PRIM_HAS_UVS : 0u);
+            const uint32_t gid_base = (uint32_t)prims.size();
+            prims.resize(prims.size() + o->tris.size());
+            for (size_t k = 0; k < perm.size(); ++k) {
+                const uint32_t face = perm[k];
+                prims[gid_base + face] = PrimRef{flags, tri_base + (uint32_t)k, (uint32_t)o->mat, inst};
+                tris.push_back(o->tris[face]);
+                tri_gid.push_back(gid_base + face);
+                if (any_attr) tri_attr.push_back(o->tri_attr.empty() ? TriAttr{} : o->tri_attr[face]);
+            }
+            break;
+        }
+        default:
+            return set_error("pt_world_build: unsupported object kind");
+        }
+        Box world = inst >= 0 ? xform_box(local, insts[inst]) : local;
+        tlas_items.push_back(BuildItem{world, world.centroid(), (uint32_t)entries.size()});
+        entries.push_back(e);
+    }
+    // Build the TLAS over world entries (one entry per leaf).
+    Builder tl{nodes, tlas_items, 1, MAX_TLAS_DEPTH, false, nullptr};
+    Box wb;
+    uint32_t tlas_root = tl.build(0, tlas_items.size(), 0, wb);
+    if (tl.depth_reached + 1 + max_blas_depth + 1 > TRAVERSAL_STACK) return set_error("pt_world_build: BVH too deep for the traversal stack");
+
+    // texture atlas
+    std::vector<TexD> tex(s->tex.size());
+    std::vector<uint8_t> atlas;
+    for (size_t i = 0; i < s->tex.size(); ++i) {
+        tex[i] = s->tex[i].d;
+        if (tex[i].kind == TEX_IMAGE) {
+            tex[i].ofs = atlas.size();
+            atlas.insert(atlas.end(), s->tex[i].image.begin(), s->tex[i].image.end());
+        }
+    }
+    SceneD v{};
+    DeviceBuffers& dev = s->dev;
+    bool ok = upload(dev, nodes, v.nodes) && upload(dev, entries, v.entries) && upload(dev, prims, v.prims) &&
+              upload(dev, spheres, v.spheres) && upload(dev, quads, v.quads) && upload(dev, tris, v.tris) &&
+              upload(dev, tri_gid, v.tri_gid) && upload(dev, insts, v.insts) && upload(dev, tex, v.tex) &&
+              upload(dev, s->mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, lights, v.lights);
+    if (ok && any_attr) ok = upload(dev, tri_attr, v.tri_attr);
+    if (!ok) {
+        dev.release();
+        return -1;
+    }
+    v.tlas_root = tlas_root;
+    v.n_entries = (uint32_t)entries.size();
+    v.n_prims = (uint32_t)prims.size();
+    v.n_lights = (uint32_t)lights.size();
+    dev.view = v;
+    s->n_prims = v.n_prims;
+    s->built = true;
+    return 0;
+}

@@ -1,0 +1,74 @@
+// Host scene graph (the builder side of World / Hittable / BxDFMaterial / Texture) and its
+// flattening into the device tables of pt_types.h.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pt_host_math.h"
+#include "pt_types.h"
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cus = 0;
+    std::string name;
+};
+
+namespace pt {
+
+int set_error(const std::string& msg);   // returns -1
+const char* last_error();
+bool hip_ok(hipError_t e, const char* what);
+
+enum ObjKind { OBJ_SPHERE, OBJ_QUAD, OBJ_CUBOID, OBJ_MESH, OBJ_INSTANCE };
+
+struct HostTex {
+    TexD d{};
+    std::vector<uint8_t> image;   // TEX_IMAGE payload (RGB8)
+    bool is_rgb = false;
+};
+struct HostObj {
+    ObjKind kind;
+    int mat = -1;
+    SphereD sphere{};
+    std::vector<QuadD> quads;       // 1 (quad) or 6 (cuboid)
+    std::vector<TriD> tris;         // mesh
+    std::vector<TriAttr> tri_attr;  // mesh with normals and/or uvs
+    bool has_normals = false, has_uvs = false;
+    int child = -1;                 // instance
+    InstD xf{};
+    bool used = false;              // already placed in the world or wrapped by an instance
+};
+
+struct DeviceBuffers {
+    std::vector<void*> allocs;
+    SceneD view{};
+    void release();
+};
+
+}  // namespace pt
+
+struct pt_scene {
+    pt_ctx* ctx = nullptr;
+    std::vector<pt::HostTex> tex;
+    std::vector<pt::MatD> mats;
+    std::vector<pt::HostObj> objs;
+    std::vector<int> world_objects, world_lights;
+    std::map<std::string, int> images;   // registered image name -> texture handle
+    bool built = false;
+    uint32_t n_prims = 0;
+    pt::DeviceBuffers dev;
+    // path pool cache (re-used across pt_render calls of the same size)
+    void* pool_mem = nullptr;
+    size_t pool_bytes = 0;
+    pt::CountersD* d_counters = nullptr;
+    pt::CountersD* h_counters = nullptr;   // pinned
+    ~pt_scene();
+};
+
+namespace pt {
+int scene_build(pt_scene* s);   // flatten + BVH + upload
+}

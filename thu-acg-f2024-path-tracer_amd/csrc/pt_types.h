@@ -1,0 +1,128 @@
+// Flattened scene + path-pool layout shared by the host scene builder and the HIP kernels.
+// Everything the kernels read lives in HBM as plain arrays of these PODs (SoA for the
+// per-path state, AoS for the small read-only scene tables that sit in L2).
+#pragma once
+#include <stdint.h>
+
+namespace pt {
+
+// ---- BVH -----------------------------------------------------------------------------
+// One node format for the top-level tree (over world objects) and every per-mesh tree.
+// Boxes are stored as f32 rounded OUTWARD from the padded f64 bounds (conservative), the
+// slab test itself runs in f64 against the f64 ray. 64 B = four 16-B loads per visit.
+// Child reference (32 bit):
+//   00xx.. internal node index
+//   01cc cfff.. triangle leaf: ccc = count-1 (1..8), f = first triangle (BLAS order)
+//   10xx.. world entry index (top-level leaf, always exactly one entry)
+//   0xFFFFFFFF empty slot, 0xC0000000 "leave instance" sentinel (stack only)
+struct alignas(16) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t child0, child1;
+    uint32_t pad0, pad1;
+};
+constexpr uint32_t REF_TYPE_MASK = 0xC0000000u;
+constexpr uint32_t REF_NODE = 0x00000000u;
+constexpr uint32_t REF_TRIS = 0x40000000u;
+constexpr uint32_t REF_ENTRY = 0x80000000u;
+constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t REF_LEAVE_INSTANCE = 0xC0000000u;
+constexpr int TRAVERSAL_STACK = 32;     // LDS entries per lane
+constexpr int MAX_BLAS_DEPTH = 20;      // enforced by the host builder
+constexpr int MAX_TLAS_DEPTH = 10;
+
+// ---- geometry ------------------------------------------------------------------------
+enum PrimKind : uint32_t { PRIM_SPHERE = 0, PRIM_QUAD = 1, PRIM_TRI = 2 };
+enum EntryKind : uint32_t { ENTRY_SPHERE = 0, ENTRY_QUAD = 1, ENTRY_CUBOID = 2, ENTRY_MESH = 3 };
+constexpr uint32_t PRIM_HAS_NORMALS = 1u << 8, PRIM_HAS_UVS = 1u << 9;
+
+struct PrimRef {         // indexed by GLOBAL primitive id (lights list first, then objects)
+    uint32_t kind;       // PrimKind | PRIM_HAS_*
+    uint32_t index;      // index into spheres[] / quads[] / tris[]
+    uint32_t mat;
+    int32_t inst;        // instance transform or -1
+};
+struct Entry {           // one per world-level object (lights list first, then objects)
+    uint32_t kind;       // EntryKind
+    uint32_t first_prim; // global id of its first primitive
+    int32_t inst;
+    uint32_t blas_root;  // node index (ENTRY_MESH)
+};
+struct SphereD { double r, p1[3], p2[3]; };
+struct QuadD { double q[3], u[3], v[3], w[3], n[3], d; };
+struct TriD { double v0[3], v1[3], v2[3]; };
+struct TriAttr { double n[3][3]; double uv[3][2]; };   // only when the mesh has them
+struct InstD { double c0[3], c1[3], c2[3], t[3], i0[3], i1[3], i2[3], it[3]; };
+
+// ---- textures / materials ------------------------------------------------------------
+enum TexKind : uint32_t { TEX_SOLID_RGB = 0, TEX_SOLID_F = 1, TEX_CHECKER = 2, TEX_IMAGE = 3 };
+struct TexD {
+    uint32_t kind, t1, t2, w, h, pad;
+    uint64_t ofs;        // byte offset into the RGB8 atlas
+    double v[3];
+    double inv_scale;
+};
+enum MatKind : uint32_t { MAT_DIFFUSE = 0, MAT_METAL = 1, MAT_GLASS = 2, MAT_PRINCIPLED = 3, MAT_LIGHT = 4 };
+struct MatD {
+    uint32_t kind;
+    int32_t color_tex, rough_tex, nmap_tex;
+    double ior;
+    // principled.rs:45-58 order: metallic, roughness, subsurface, specular, specular_tint,
+    // ior, spec_trans, sheen, sheen_tint, clearcoat, clearcoat_gloss
+    double p[11];
+    double lobe_w[4], lobe_p[4], alpha_g;   // principled.rs:75-100, precomputed on the host
+};
+
+// ---- camera --------------------------------------------------------------------------
+struct CamD {
+    double center[3], pixel00[3], pixel_du[3], pixel_dv[3], dof_right[3], dof_up[3];
+    double blur_strength;
+    double env_color[3];
+    double two_pi_scale;     // rand's UniformFloat scale for gen_range(0.0..=2pi)
+    uint32_t width, height, max_depth, env_is_map;
+    int32_t env_tex;
+    uint32_t n_lights;
+};
+
+struct SceneD {
+    const BvhNode* nodes;
+    const Entry* entries;
+    const PrimRef* prims;
+    const SphereD* spheres;
+    const QuadD* quads;
+    const TriD* tris;
+    const TriAttr* tri_attr;     // parallel to tris when any mesh has normals/uvs, else null
+    const uint32_t* tri_gid;     // BLAS-order triangle -> global primitive id
+    const InstD* insts;
+    const TexD* tex;
+    const MatD* mats;
+    const uint8_t* atlas;
+    const uint32_t* lights;      // entry indices of the lights list
+    uint32_t tlas_root;          // child reference of the top-level root
+    uint32_t n_entries, n_prims, n_lights;
+};
+
+// ---- path pool (SoA, one slot per resident path) ---------------------------------------
+// Slot s owns pixel (s % n_pixels) and renders samples spp_begin + (s / n_pixels) + j*k.
+constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
+constexpr uint32_t SLOT_DEAD = 0xFFFFFFFFu;   // value of `bounce` for a finished slot
+struct PoolD {
+    double *ox, *oy, *oz, *dx, *dy, *dz, *time;   // current ray (direction normalised)
+    double *tx, *ty, *tz;                         // throughput
+    double *rx, *ry, *rz;                         // radiance of the sample in flight
+    double *ax, *ay, *az;                         // sum over this slot's finished samples
+    double* hit_t;
+    uint32_t* hit_prim;
+    uint32_t *sample, *bounce, *draw;
+    uint32_t n_slots, n_pixels, k;                // k = slots per pixel
+    uint32_t spp_begin, spp_end;
+};
+
+struct CountersD {
+    unsigned long long alive;        // slots still rendering
+    unsigned long long segments;     // extend() calls on live paths
+    unsigned long long samples;      // finished samples
+    unsigned long long pad;
+};
+
+}  // namespace pt

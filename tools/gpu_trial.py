@@ -1,0 +1,40 @@
+"""Scratch driver used during bring-up: product (GPU) vs oracle (CPU) on small renders."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+pt = importlib.import_module("thu-acg-f2024-path-tracer_amd")
+import oracle_py as orc
+
+def images_for(scene_id):
+    return {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt._SCENE_IMAGES.get(scene_id, [])}
+
+def compare(ctx, scene_id, width, spp, k=1, save=None):
+    t = time.time()
+    gs = pt.Scene(ctx); gcam = gs.build_scene(scene_id, width, spp)
+    tb = time.time() - t
+    os_ = orc.Scene(); ocam = os_.build_scene(scene_id, width, spp, images=images_for(scene_id))
+    t = time.time(); ga, st = gs.render(gcam, 1, 0, spp, slots_per_pixel=k, profile=True); tg = time.time() - t
+    t = time.time(); oa, cnt = os_.render(ocam, 1, 0, spp); to = time.time() - t
+    d = np.abs(ga - oa)
+    rel = d / (1e-300 + np.maximum(np.abs(oa), 1.0))
+    H = ga.shape[0]
+    print(f"scene {scene_id} {width}x{H}@{spp} k={st.slots_per_pixel}: gpu build {tb:.2f}s render {tg:.3f}s ({st.ms_total:.1f} ms, {width*H*spp/st.ms_total/1e3:.2f} Msamples/s) "
+          f"oracle {to:.2f}s ({width*H*spp/to/1e6:.2f} Ms/s) | seg gpu {st.segments} orc {cnt['segments']} | "
+          f"max abs {np.nanmax(d):.3e} max rel {np.nanmax(rel):.3e} rmse(mean img) {np.sqrt(np.nanmean((d/spp)**2)):.3e} exact {np.mean(ga==oa):.4f} nan g/o {np.isnan(ga).sum()}/{np.isnan(oa).sum()}")
+    print("   stats", {k_: v for k_, v in st.as_dict().items() if k_.startswith(('ms_', 'iter', 'launch', 'blocks', 'n_slots'))})
+    if save:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        pt.save_png(os.path.join(ROOT, "gpurun_out", save), ctx.resolve_u8(ga, spp))
+    bad = np.argwhere(rel.max(axis=2) > 1e-6)
+    for (y, x) in bad[:5]:
+        print("   mismatch pixel", y, x, ga[y, x], oa[y, x])
+    gs.close(); os_.close()
+    return ga, oa
+
+if __name__ == "__main__":
+    ctx = pt.Context(0)
+    print(ctx.name())
+    for arg in sys.argv[1:]:
+        sid, w, spp, k = (list(map(int, arg.split(","))) + [1])[:4]
+        compare(ctx, sid, w, spp, k, save=f"trial_s{sid}.png")
