@@ -92,6 +92,13 @@ int orc_trace_sample(orc_scene*, const orc_camera*, uint64_t seed, uint32_t pixe
 /* camera.rs:109-114,128-130 */
 void orc_resolve_u8(const double* accum, uint32_t n_pixels, uint32_t total_spp, uint8_t* rgb8);
 
+/* elementary functions: 0 = platform libm (faithful to the Rust reference, default),
+ * 1 = deterministic fdlibm-style set shared with the GPU kernels (bit-exact parity mode) */
+void orc_set_math_mode(int det);
+int orc_get_math_mode(void);
+/* det-math probe: which = 3 sin 4 cos 5 acos 6 atan2(a,b) 7 pow(a,b) 8 log2 10 log 11 exp */
+double orc_detmath(int which, double a, double b);
+
 /* scalar probes used by the known-answer tests */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);

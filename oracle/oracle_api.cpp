@@ -14,6 +14,23 @@
 
 using namespace orc;
 
+int orc::g_math_mode = 0;
+extern "C" void orc_set_math_mode(int det) { orc::g_math_mode = det ? 1 : 0; }
+extern "C" int orc_get_math_mode(void) { return orc::g_math_mode; }
+extern "C" double orc_detmath(int which, double a, double b) {
+    switch (which) {
+    case 3: return detmath::sin(a);
+    case 4: return detmath::cos(a);
+    case 5: return detmath::acos(a);
+    case 6: return detmath::atan2(a, b);
+    case 7: return detmath::pow(a, b);
+    case 8: return detmath::log2(a);
+    case 10: return detmath::log(a);
+    case 11: return detmath::exp(a);
+    }
+    return std::nan("");
+}
+
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
     g_err = m;

@@ -90,6 +90,10 @@ def _load():
     lib.orc_load_hdr_rgb8.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.orc_free.argtypes = [C.c_void_p]
     lib.orc_free.restype = None
+    lib.orc_set_math_mode.argtypes = [C.c_int]
+    lib.orc_set_math_mode.restype = None
+    lib.orc_detmath.argtypes = [C.c_int, C.c_double, C.c_double]
+    lib.orc_detmath.restype = C.c_double
     return lib
 
 
@@ -104,6 +108,16 @@ def _check(rc, what="oracle call"):
 
 def _d3(v):
     return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def set_math_mode(det: bool):
+    """False: platform libm (faithful to the Rust reference). True: the deterministic
+    elementary functions the GPU kernels use (bit-exact parity mode)."""
+    lib.orc_set_math_mode(1 if det else 0)
+
+
+def detmath(which: int, a: float, b: float = 0.0) -> float:
+    return lib.orc_detmath(which, a, b)
 
 
 def probe(which: int, *args: float) -> float:

@@ -161,7 +161,7 @@ inline V3 cosine_sample_hemisphere(Rng& rng) {  // sampling.rs:18-24 (phi first,
     double phi = rng.gen_range_inclusive(2.0 * PI);
     double r2 = rng.gen();
     double r2s = std::sqrt(r2);
-    return V3{r2s * std::cos(phi), r2s * std::sin(phi), std::sqrt(1.0 - r2)};
+    return V3{r2s * m_cos(phi), r2s * m_sin(phi), std::sqrt(1.0 - r2)};
 }
 namespace ggx {  // sampling.rs:30-117
 inline double D(V3 h, double roughness) {
@@ -185,8 +185,8 @@ inline V3 sample_ggx_vndf(V3 v_in, double a2, Rng& rng) {  // sampling.rs:65-94
     double a = 1.0 / (1.0 + v.z);
     double r = std::sqrt(e1);
     double phi = e2 < a ? e2 / a * PI : PI + (e2 - a) / (1.0 - a) * PI;
-    double p1 = r * std::cos(phi);
-    double p2 = r * std::sin(phi) * (e2 < a ? 1.0 : v.z);
+    double p1 = r * m_cos(phi);
+    double p2 = r * m_sin(phi) * (e2 < a ? 1.0 : v.z);
     V3 n = p1 * t1 + p2 * t2 + std::sqrt(fmax2(1.0 - p1 * p1 - p2 * p2, 0.0)) * v;
     return normalize(V3{a2 * n.x, a2 * n.y, fmax2(n.z, 0.0)});
 }
@@ -199,16 +199,16 @@ namespace gtr1 {  // sampling.rs:113-143 (Q3: log2, caller passes |l.h|)
 inline double D(double abs_cos_theta, double alpha_g) {
     double alpha2 = alpha_g * alpha_g;
     double t = 1.0 + (alpha2 - 1.0) * abs_cos_theta * abs_cos_theta;
-    return (alpha2 - 1.0) / (PI * t * std::log2(alpha2));
+    return (alpha2 - 1.0) / (PI * t * m_log2(alpha2));
 }
 inline V3 sample_microfacet_normal(double alpha, Rng& rng) {
     double e1 = rng.gen();
     double e2 = rng.gen();
     double alpha2 = alpha * alpha;
-    double cos_theta = (1.0 - std::pow(alpha2, 1.0 - e1)) / (1.0 - alpha2);
+    double cos_theta = (1.0 - m_pow(alpha2, 1.0 - e1)) / (1.0 - alpha2);
     double sin_theta = std::sqrt(fmax2(1.0 - cos_theta * cos_theta, 0.0));
     double phi = 2.0 * PI * e2;
-    V3 h{sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta};
+    V3 h{sin_theta * m_cos(phi), sin_theta * m_sin(phi), cos_theta};
     return h.z < 0.0 ? -h : h;
 }
 }  // namespace gtr1
@@ -604,8 +604,8 @@ struct Sphere : Hittable {  // sphere.rs
         if (t > ray_t.cull) return false;
         V3 point = ray.at(t);
         V3 normal = normalize(point - center);
-        double theta = std::acos(-normal.y);                  // get_uv :52-56
-        double phi = std::atan2(-normal.z, normal.x) + PI;
+        double theta = m_acos(-normal.y);                  // get_uv :52-56
+        double phi = m_atan2(-normal.z, normal.x) + PI;
         out = make_hit(ray, point, normal, t, mat.get(), phi / (2.0 * PI), theta / PI, id);
         return true;
     }
@@ -613,8 +613,8 @@ struct Sphere : Hittable {  // sphere.rs
     bool sample(V3 origin, double time, Rng& rng, V3& dir) const override {  // :110-122
         double u = rng.gen(), v = rng.gen();
         double theta = 2.0 * PI * u;
-        double phi = std::acos(2.0 * v - 1.0);
-        double x = std::sin(phi) * std::cos(theta), y = std::sin(phi) * std::sin(theta), z = std::cos(phi);
+        double phi = m_acos(2.0 * v - 1.0);
+        double x = m_sin(phi) * m_cos(theta), y = m_sin(phi) * m_sin(theta), z = m_cos(phi);
         V3 point = position(time) + V3{x, y, z} * radius;
         dir = normalize(point - origin);
         return true;
@@ -1032,13 +1032,13 @@ struct Camera {
     static void random_offsets(Rng& rng, double& ox, double& oy) {  // :133-138
         double radius = std::sqrt(rng.gen());
         double angle = rng.gen() * 2.0 * PI;
-        ox = radius * std::cos(angle);
-        oy = radius * std::sin(angle);
+        ox = radius * m_cos(angle);
+        oy = radius * m_sin(angle);
     }
     V3 sample_environment(const Ray& ray) const {  // :140-151
         if (!env_is_map) return env_color;
-        double theta = std::acos(ray.d.y);
-        double phi = std::atan2(ray.d.z, ray.d.x);
+        double theta = m_acos(ray.d.y);
+        double phi = m_atan2(ray.d.z, ray.d.x);
         double u = (phi + PI) / (2.0 * PI);
         double v = 1.0 - theta / PI;
         return env_map->value(u, v, V3{0, 0, 0});

@@ -13,7 +13,21 @@
 #include <cmath>
 #include <cstdint>
 
+#include "orc_detmath.h"
+
 namespace orc {
+
+// Elementary-function back end. 0 = the platform libm (what the Rust reference calls through
+// f64::sin etc. — the faithful mode, used for the CPU baseline and the tolerance tests);
+// 1 = the deterministic fdlibm-style set the GPU kernels use (orc_detmath.h), which makes
+// oracle and GPU agree bit for bit. Selected with orc_set_math_mode().
+extern int g_math_mode;
+inline double m_sin(double x) { return g_math_mode ? detmath::sin(x) : std::sin(x); }
+inline double m_cos(double x) { return g_math_mode ? detmath::cos(x) : std::cos(x); }
+inline double m_acos(double x) { return g_math_mode ? detmath::acos(x) : std::acos(x); }
+inline double m_atan2(double y, double x) { return g_math_mode ? detmath::atan2(y, x) : std::atan2(y, x); }
+inline double m_pow(double x, double y) { return g_math_mode ? detmath::pow(x, y) : std::pow(x, y); }
+inline double m_log2(double x) { return g_math_mode ? detmath::log2(x) : std::log2(x); }
 
 constexpr double PI = 3.14159265358979323846264338327950288;  // std::f64::consts::PI
 

@@ -1,0 +1,394 @@
+// Deterministic f64 elementary functions: sin/cos, acos, atan2, log, log2, exp, pow.
+//
+// Why: the integrator has discontinuities that turn a 1-ulp difference between two libm
+// implementations into a visibly different sample (the 3-D checker on the y = 0 ground plane
+// floors a coordinate that is 0 +- 1e-16, texture.rs:44-48; the light-plane offset sign,
+// camera.rs:217). With these functions the GPU kernels and the CPU oracle (in its "det" math
+// mode) execute the SAME sequence of IEEE-754 operations (+ - * / sqrt, no FMA, no tables
+// beyond the listed constants), so their results agree bit for bit and parity tests can
+// demand equality instead of a tolerance.
+//
+// Algorithms: the classic fdlibm (Sun Microsystems, freely redistributable) kernels —
+// k_sin/k_cos with a 3-part Cody-Waite reduction (valid for |x| < 2^19*pi/2; larger or
+// non-finite arguments, which the renderer never produces, fall back to an fmod-style
+// reduction), e_acos, s_atan/e_atan2, e_log, e_exp. log2(x) = log(x)/ln2 and
+// pow(x,y) = exp(y*log(x)) (x > 0) are composed from those (<= 4 ulp for |y log x| <= 4; the
+// renderer only calls pow(0.0625, y), y in (0,1]). Accuracy of each is pinned against glibc
+// in tests/test_detmath.py.
+//
+// This file is compiled for host and device; oracle/orc_detmath.h is a verbatim copy (the
+// oracle may not include product headers and vice versa; a test keeps the two in sync).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PT_DM __host__ __device__ inline
+#else
+#define PT_DM inline
+#endif
+
+namespace detmath {
+
+PT_DM uint64_t dm_bits(double x) {
+    uint64_t u;
+    __builtin_memcpy(&u, &x, 8);
+    return u;
+}
+PT_DM double dm_from_bits(uint64_t u) {
+    double x;
+    __builtin_memcpy(&x, &u, 8);
+    return x;
+}
+PT_DM int32_t dm_hi(double x) { return (int32_t)(dm_bits(x) >> 32); }
+PT_DM uint32_t dm_lo(double x) { return (uint32_t)dm_bits(x); }
+PT_DM double dm_words(int32_t hi, uint32_t lo) { return dm_from_bits(((uint64_t)(uint32_t)hi << 32) | lo); }
+PT_DM double dm_abs(double x) { return dm_from_bits(dm_bits(x) & 0x7FFFFFFFFFFFFFFFull); }
+PT_DM double dm_nan() { return dm_from_bits(0x7FF8000000000000ull); }
+PT_DM double dm_sqrt(double x) { return __builtin_sqrt(x); }   // IEEE correctly rounded on both sides
+
+// ---- sin / cos ------------------------------------------------------------------------
+PT_DM double dm_ksin(double x, double y, int iy) {   // |x| <= pi/4, y = tail
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x;
+    double v = z * x;
+    double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    if (iy == 0) return x + v * (S1 + z * r);
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+PT_DM double dm_kcos(double x, double y) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    int32_t ix = dm_hi(x) & 0x7fffffff;
+    if (ix < 0x3e400000) {
+        if ((int)x == 0) return 1.0;
+    }
+    double z = x * x;
+    double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    if (ix < 0x3FD33333) return 1.0 - (0.5 * z - (z * r - x * y));
+    double qx;
+    if (ix > 0x3fe90000) qx = 0.28125;
+    else qx = dm_words(ix - 0x00200000, 0);
+    double hz = 0.5 * z - qx;
+    double a = 1.0 - qx;
+    return a - (hz - (z * r - x * y));
+}
+// argument reduction: x = n*(pi/2) + (y0 + y1), returns n mod 4 ... (n as int)
+PT_DM int dm_rem_pio2(double x, double& y0, double& y1) {
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11,
+                 pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21, pio2_3 = 2.02226624871116645580e-21,
+                 pio2_3t = 8.47842766036889956997e-32;
+    int32_t hx = dm_hi(x);
+    int32_t ix = hx & 0x7fffffff;
+    if (ix <= 0x3fe921fb) {   // |x| <= pi/4
+        y0 = x;
+        y1 = 0.0;
+        return 0;
+    }
+    if (ix >= 0x7ff00000) {   // inf / nan
+        y0 = y1 = x - x;
+        return 0;
+    }
+    double ax = dm_abs(x);
+    if (ix > 0x413921fb) {
+        // |x| > 2^19*pi/2: outside the renderer's domain. Deterministic, reduced-accuracy path.
+        const double two_pi = 6.28318530717958647692528676655900577;
+        double q = ax / two_pi;
+        double fq = (double)(int64_t)q;   // q < 2^63 assumed; beyond that precision is gone anyway
+        if (!(q < 9.0e18)) {
+            y0 = y1 = dm_nan();
+            return 0;
+        }
+        ax = ax - fq * two_pi;
+        if (ax < 0.0) ax = 0.0;
+    }
+    // medium size: Cody-Waite with up to three 33-bit pieces of pi/2
+    int32_t n = (int32_t)(ax * invpio2 + 0.5);
+    double fn = (double)n;
+    double r = ax - fn * pio2_1;
+    double w = fn * pio2_1t;
+    int32_t j = (dm_hi(ax) & 0x7fffffff) >> 20;
+    y0 = r - w;
+    int32_t i = j - ((dm_hi(y0) >> 20) & 0x7ff);
+    if (i > 16) {   // 2nd iteration needed, good to 118 bits
+        double t = r;
+        w = fn * pio2_2;
+        r = t - w;
+        w = fn * pio2_2t - ((t - r) - w);
+        y0 = r - w;
+        i = j - ((dm_hi(y0) >> 20) & 0x7ff);
+        if (i > 49) {   // 3rd iteration, 151 bits
+            t = r;
+            w = fn * pio2_3;
+            r = t - w;
+            w = fn * pio2_3t - ((t - r) - w);
+            y0 = r - w;
+        }
+    }
+    y1 = (r - y0) - w;
+    if (hx < 0) {
+        y0 = -y0;
+        y1 = -y1;
+        return -n;
+    }
+    return n;
+}
+PT_DM void sincos(double x, double& s, double& c) {
+    double y0, y1;
+    int n = dm_rem_pio2(x, y0, y1);
+    int32_t ix = dm_hi(x) & 0x7fffffff;
+    if (ix <= 0x3fe921fb) {
+        s = dm_ksin(x, 0.0, 0);
+        c = dm_kcos(x, 0.0);
+        return;
+    }
+    double ks = dm_ksin(y0, y1, 1), kc = dm_kcos(y0, y1);
+    switch (n & 3) {
+    case 0: s = ks; c = kc; break;
+    case 1: s = kc; c = -ks; break;
+    case 2: s = -ks; c = -kc; break;
+    default: s = -kc; c = ks; break;
+    }
+}
+PT_DM double sin(double x) { double s, c; sincos(x, s, c); return s; }
+PT_DM double cos(double x) { double s, c; sincos(x, s, c); return c; }
+
+// ---- acos -----------------------------------------------------------------------------
+PT_DM double acos(double x) {
+    const double pi = 3.14159265358979311600e+00, pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+                 pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+                 pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+                 qS4 = 7.70381505559019352791e-02;
+    int32_t hx = dm_hi(x);
+    int32_t ix = hx & 0x7fffffff;
+    if (ix >= 0x3ff00000) {   // |x| >= 1
+        if (((uint32_t)(ix - 0x3ff00000) | dm_lo(x)) == 0) {
+            if (hx > 0) return 0.0;
+            return pi + 2.0 * pio2_lo;
+        }
+        return dm_nan();
+    }
+    if (ix < 0x3fe00000) {   // |x| < 0.5
+        if (ix <= 0x3c600000) return pio2_hi + pio2_lo;
+        double z = x * x;
+        double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        double r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) {   // x < -0.5
+        double z = (1.0 + x) * 0.5;
+        double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        double s = dm_sqrt(z);
+        double r = p / q;
+        double w = r * s - pio2_lo;
+        return pi - 2.0 * (s + w);
+    }
+    // x > 0.5
+    double z = (1.0 - x) * 0.5;
+    double s = dm_sqrt(z);
+    double df = dm_words(dm_hi(s), 0);
+    double c = (z - df * df) / (s + df);
+    double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    double r = p / q;
+    double w = r * s + c;
+    return 2.0 * (df + w);
+}
+
+// ---- atan / atan2 ---------------------------------------------------------------------
+PT_DM double atan(double x) {
+    const double hi0 = 4.63647609000806093515e-01, hi1 = 7.85398163397448278999e-01, hi2 = 9.82793723247329054082e-01,
+                 hi3 = 1.57079632679489655800e+00;
+    const double lo0 = 2.26987774529616870924e-17, lo1 = 3.06161699786838301793e-17, lo2 = 1.39033110312309984516e-17,
+                 lo3 = 6.12323399573676603587e-17;
+    const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
+                 aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                 aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
+                 aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+    int32_t hx = dm_hi(x);
+    int32_t ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x44100000) {   // |x| >= 2^66
+        if (ix > 0x7ff00000 || (ix == 0x7ff00000 && dm_lo(x) != 0)) return x + x;   // NaN
+        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+    }
+    if (ix < 0x3fdc0000) {   // |x| < 0.4375
+        if (ix < 0x3e200000) return x;   // |x| < 2^-29
+        id = -1;
+    } else {
+        x = dm_abs(x);
+        if (ix < 0x3ff30000) {   // |x| < 1.1875
+            if (ix < 0x3fe60000) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); }
+            else { id = 1; x = (x - 1.0) / (x + 1.0); }
+        } else {
+            if (ix < 0x40038000) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); }
+            else { id = 3; x = -1.0 / x; }
+        }
+    }
+    double z = x * x;
+    double w = z * z;
+    double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    double ahi = id == 0 ? hi0 : id == 1 ? hi1 : id == 2 ? hi2 : hi3;
+    double alo = id == 0 ? lo0 : id == 1 ? lo1 : id == 2 ? lo2 : lo3;
+    z = ahi - ((x * (s1 + s2) - alo) - x);
+    return hx < 0 ? -z : z;
+}
+PT_DM double atan2(double y, double x) {
+    const double tiny = 1.0e-300, pi_o_4 = 7.8539816339744827900E-01, pi_o_2 = 1.5707963267948965580E+00,
+                 pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
+    int32_t hx = dm_hi(x), hy = dm_hi(y);
+    int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    uint32_t lx = dm_lo(x), ly = dm_lo(y);
+    if (((uint32_t)ix | ((lx | (0u - lx)) >> 31)) > 0x7ff00000u || ((uint32_t)iy | ((ly | (0u - ly)) >> 31)) > 0x7ff00000u) return x + y;   // NaN
+    if ((((uint32_t)hx - 0x3ff00000u) | lx) == 0) return atan(y);   // x == 1.0
+    int m = (int)(((uint32_t)hy >> 31) & 1u) | (int)(((uint32_t)hx >> 30) & 2u);   // 2*sign(x) + sign(y)
+    if (((uint32_t)iy | ly) == 0) {   // y == 0
+        switch (m) {
+        case 0:
+        case 1: return y;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (((uint32_t)ix | lx) == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;   // x == 0
+    if (ix == 0x7ff00000) {
+        if (iy == 0x7ff00000) {
+            switch (m) {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0 * pi_o_4 + tiny;
+            default: return -3.0 * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+        case 0: return 0.0;
+        case 1: return -0.0;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7ff00000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    int32_t k = (iy - ix) >> 20;
+    double z;
+    if (k > 60) {
+        z = pi_o_2 + 0.5 * pi_lo;
+        m &= 1;
+    } else if (hx < 0 && k < -60) {
+        z = 0.0;
+    } else {
+        z = atan(dm_abs(y / x));
+    }
+    switch (m) {
+    case 0: return z;
+    case 1: return -z;
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
+// ---- log / log2 -----------------------------------------------------------------------
+PT_DM double log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, two54 = 1.80143985094819840000e+16,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int32_t hx = dm_hi(x);
+    uint32_t lx = dm_lo(x);
+    int32_t k = 0;
+    if (hx < 0x00100000) {   // x < 2^-1022
+        if ((((uint32_t)hx & 0x7fffffffu) | lx) == 0) return -two54 / 0.0;   // log(+-0) = -inf
+        if (hx < 0) return dm_nan();                                        // log(-#) = NaN
+        k -= 54;
+        x *= two54;
+        hx = dm_hi(x);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    x = dm_words(hx | (i ^ 0x3ff00000), dm_lo(x));   // normalise x or x/2
+    k += (i >> 20);
+    double f = x - 1.0;
+    double dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {   // |f| < 2^-20
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            return dk * ln2_hi + dk * ln2_lo;
+        }
+        double R = f * f * (0.5 - 0.33333333333333333 * f);
+        if (k == 0) return f - R;
+        return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    double s = f / (2.0 + f);
+    double z = s * s;
+    i = hx - 0x6147a;
+    double w = z * z;
+    int32_t j = 0x6b851 - hx;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j;
+    double R = t2 + t1;
+    if (i > 0) {
+        double hfsq = 0.5 * f * f;
+        if (k == 0) return f - (hfsq - s * (hfsq + R));
+        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    if (k == 0) return f - s * (f - R);
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+PT_DM double log2(double x) { return log(x) / 6.93147180559945286227e-01; }
+
+// ---- exp / pow ------------------------------------------------------------------------
+PT_DM double exp(double x) {
+    const double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
+                 ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
+                 P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08, twom1000 = 9.33263618503218878990e-302;
+    uint32_t hx = (uint32_t)dm_hi(x);
+    int xsb = (int)((hx >> 31) & 1u);
+    hx &= 0x7fffffffu;
+    double hi = 0.0, lo = 0.0;
+    int32_t k = 0;
+    if (hx >= 0x40862E42u) {   // |x| >= 709.78
+        if (hx >= 0x7ff00000u) {
+            if (((hx & 0xfffffu) | dm_lo(x)) != 0) return x + x;   // NaN
+            return xsb == 0 ? x : 0.0;
+        }
+        if (x > o_threshold) return 1.0e300 * 1.0e300;
+        if (x < u_threshold) return twom1000 * twom1000;
+    }
+    if (hx > 0x3fd62e42u) {   // |x| > 0.5 ln2
+        if (hx < 0x3FF0A2B2u) {
+            hi = x - (xsb ? -ln2HI : ln2HI);
+            lo = xsb ? -ln2LO : ln2LO;
+            k = 1 - xsb - xsb;
+        } else {
+            k = (int32_t)(invln2 * x + (xsb ? -0.5 : 0.5));
+            double t = (double)k;
+            hi = x - t * ln2HI;
+            lo = t * ln2LO;
+        }
+        x = hi - lo;
+    } else if (hx < 0x3e300000u) {   // |x| < 2^-28
+        return 1.0 + x;
+    }
+    double t = x * x;
+    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    if (k >= -1021) return dm_words(dm_hi(y) + (int32_t)((uint32_t)k << 20), dm_lo(y));
+    y = dm_words(dm_hi(y) + (int32_t)((uint32_t)(k + 1000) << 20), dm_lo(y));
+    return y * twom1000;
+}
+// x > 0 only (the renderer's single use: GTR1 sampling, sampling.rs:132)
+PT_DM double pow(double x, double y) {
+    if (!(x > 0.0)) return dm_nan();
+    return exp(y * log(x));
+}
+
+}  // namespace detmath

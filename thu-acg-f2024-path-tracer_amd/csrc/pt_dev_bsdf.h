@@ -104,7 +104,7 @@ PT_DEV double ggx_G1(V3 w, double roughness) {
 PT_DEV double gtr1_D(double abs_cos_theta, double alpha_g) {
     double alpha2 = alpha_g * alpha_g;
     double t = 1.0 + (alpha2 - 1.0) * abs_cos_theta * abs_cos_theta;
-    return (alpha2 - 1.0) / (D_PI * t * log2(alpha2));
+    return (alpha2 - 1.0) / (D_PI * t * detmath::log2(alpha2));
 }
 PT_DEV V3 cosine_sample_hemisphere(Rng& rng, double two_pi_scale) {   // sampling.rs:18-24
     uint64_t a, b;
@@ -113,7 +113,7 @@ PT_DEV V3 cosine_sample_hemisphere(Rng& rng, double two_pi_scale) {   // samplin
     double r2 = u64_to_unit(b);
     double r2s = sqrt(r2);
     double sn, cs;
-    sincos(phi, &sn, &cs);
+    detmath::sincos(phi, sn, cs);
     return V3{r2s * cs, r2s * sn, sqrt(1.0 - r2)};
 }
 PT_DEV V3 ggx_sample_microfacet_normal(V3 v_in, double roughness, Rng& rng) {   // sampling.rs:57-94
@@ -128,7 +128,7 @@ PT_DEV V3 ggx_sample_microfacet_normal(V3 v_in, double roughness, Rng& rng) {   
     double r = sqrt(e1);
     double phi = e2 < a ? e2 / a * D_PI : D_PI + (e2 - a) / (1.0 - a) * D_PI;
     double sn, cs;
-    sincos(phi, &sn, &cs);
+    detmath::sincos(phi, sn, cs);
     double p1 = r * cs;
     double p2 = r * sn * (e2 < a ? 1.0 : v.z);
     V3 n = p1 * t1 + p2 * t2 + sqrt(fmax(1.0 - p1 * p1 - p2 * p2, 0.0)) * v;
@@ -140,11 +140,11 @@ PT_DEV V3 gtr1_sample_microfacet_normal(double alpha, Rng& rng) {   // sampling.
     rng_u64x2(rng, ua, ub);
     double e1 = u64_to_unit(ua), e2 = u64_to_unit(ub);
     double alpha2 = alpha * alpha;
-    double cos_theta = (1.0 - pow(alpha2, 1.0 - e1)) / (1.0 - alpha2);
+    double cos_theta = (1.0 - detmath::pow(alpha2, 1.0 - e1)) / (1.0 - alpha2);
     double sin_theta = sqrt(fmax(1.0 - cos_theta * cos_theta, 0.0));
     double phi = 2.0 * D_PI * e2;
     double sn, cs;
-    sincos(phi, &sn, &cs);
+    detmath::sincos(phi, sn, cs);
     V3 h{sin_theta * cs, sin_theta * sn, cos_theta};
     return h.z < 0.0 ? -h : h;
 }

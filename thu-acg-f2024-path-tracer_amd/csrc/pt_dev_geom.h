@@ -108,8 +108,8 @@ PT_DEV bool reconstruct_hit(const SceneD& sc, const RayD& world_ray, uint32_t gi
         if (!hit_sphere(sc.spheres[pr.index], r, t_min, t, c)) return false;
         V3 point = ray_at(r, t);
         V3 normal = normalize(point - c);
-        double theta = acos(-normal.y);                       // sphere.rs:52-56
-        double phi = atan2(-normal.z, normal.x) + D_PI;
+        double theta = detmath::acos(-normal.y);                       // sphere.rs:52-56
+        double phi = detmath::atan2(-normal.z, normal.x) + D_PI;
         finish_hit(sc, r, point, normal, t, pr.mat, phi / (2.0 * D_PI), theta / D_PI, h);
     } else if (kind == PRIM_QUAD) {
         double t, a, b;
@@ -159,8 +159,8 @@ PT_DEV V3 lights_sample(const SceneD& sc, V3 origin, double time, Rng& rng) {
     }
     const SphereD& s = sc.spheres[pr.index];                  // sphere.rs:110-122
     double theta = 2.0 * D_PI * a;
-    double phi = acos(2.0 * b - 1.0);
-    double x = sin(phi) * cos(theta), y = sin(phi) * sin(theta), z = cos(phi);
+    double phi = detmath::acos(2.0 * b - 1.0);
+    double x = detmath::sin(phi) * detmath::cos(theta), y = detmath::sin(phi) * detmath::sin(theta), z = detmath::cos(phi);
     V3 center = ld3(s.p1) + (ld3(s.p2) - ld3(s.p1)) * time;
     V3 point = center + V3{x, y, z} * s.r;
     return normalize(point - origin);
@@ -206,7 +206,7 @@ PT_DEV void random_offsets(Rng& rng, double& ox, double& oy) {
     double radius = sqrt(u64_to_unit(a));
     double angle = u64_to_unit(b) * 2.0 * D_PI;
     double sn, cs;
-    sincos(angle, &sn, &cs);
+    detmath::sincos(angle, sn, cs);
     ox = radius * cs;
     oy = radius * sn;
 }
@@ -225,8 +225,8 @@ PT_DEV RayD generate_ray(const CamD& cam, uint32_t row, uint32_t col, Rng& rng) 
 // camera.rs:140-151
 PT_DEV V3 sample_environment(const SceneD& sc, const CamD& cam, V3 d) {
     if (!cam.env_is_map) return ld3(cam.env_color);
-    double theta = acos(d.y);
-    double phi = atan2(d.z, d.x);
+    double theta = detmath::acos(d.y);
+    double phi = detmath::atan2(d.z, d.x);
     double u = (phi + D_PI) / (2.0 * D_PI);
     double v = 1.0 - theta / D_PI;
     return tex_image(sc, sc.tex[cam.env_tex], u, v);

@@ -3,10 +3,13 @@
 // written operation — the translation unit is built with -ffp-contract=off — in the
 // operation order of the reference's expressions (glam 0.29 semantics, vec3.rs,
 // bsdf/sampling.rs:8-16), so results are reproducible to the last bit except for the
-// libm calls (sin/cos/acos/atan2/pow/log2 come from ROCm's OCML here).
+// elementary functions, which come from pt_detmath.h (deterministic, shared with the oracle's
+// "det" mode) — so a whole render is reproducible bit for bit on the CPU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "pt_detmath.h"
 
 #define PT_DEV __device__ __forceinline__
 

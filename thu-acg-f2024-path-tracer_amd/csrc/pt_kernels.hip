@@ -292,12 +292,14 @@ __global__ void k_math_probe(int which, const double* in, uint32_t n, double* ou
         case 0: r = sqrt(a); break;
         case 1: r = a / b; break;
         case 2: r = a * b + a; break;      // must NOT be fused
-        case 3: r = sin(a); break;
-        case 4: r = cos(a); break;
-        case 5: r = acos(a); break;
-        case 6: r = atan2(a, b); break;
-        case 7: r = pow(a, b); break;
-        case 8: r = log2(a); break;
+        case 3: r = detmath::sin(a); break;
+        case 4: r = detmath::cos(a); break;
+        case 5: r = detmath::acos(a); break;
+        case 6: r = detmath::atan2(a, b); break;
+        case 7: r = detmath::pow(a, b); break;
+        case 8: r = detmath::log2(a); break;
+        case 10: r = detmath::log(a); break;
+        case 11: r = detmath::exp(a); break;
         case 9: {
             Rng g{(uint32_t)(long long)a, 0u, (uint32_t)(long long)b, 7u, (uint32_t)i};
             r = rng_f64(g);

@@ -289,7 +289,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(render)")) return -1;
         timer.drain();
         alive = s->h_counters->alive != 0;
-        if (iterations > max_iterations) return set_error("pt_render: iteration bound exceeded (internal error)");
+        if (alive && iterations > max_iterations + 128) return set_error("pt_render: iteration bound exceeded (internal error)");
         if (poll_every < 64) poll_every *= 2;
     }
     timer.begin(2, st);

@@ -35,6 +35,7 @@ def compare(ctx, scene_id, width, spp, k=1, save=None):
 if __name__ == "__main__":
     ctx = pt.Context(0)
     print(ctx.name())
+    orc.set_math_mode(os.environ.get("ORC_LIBM", "0") != "1")
     for arg in sys.argv[1:]:
         sid, w, spp, k = (list(map(int, arg.split(","))) + [1])[:4]
         compare(ctx, sid, w, spp, k, save=f"trial_s{sid}.png")
