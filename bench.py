@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the per-pixel integrator (Camera::render, camera.rs:79) on
+BASELINE.json's headline config: scene 6 (OBJ meshes + envmap), 1920x1080 @ 4000 spp, f64.
+
+One "step" = one complete pass of the hot path over one frame: every rank renders its contiguous
+slice of the 4000 samples of every pixel (spp sharding, strong scaling: total work is fixed) into
+its own SUM accumulator, then ONE reduce (RCCL over xGMI, via torch.distributed's "nccl" backend)
+adds the accumulators on rank 0. N=1 renders all 4000 spp on one GPU and does no collective.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp 4000] [--width 1920] [--scene 6]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0. `roofline` is measured live with HIP events on the launch stream
+(pt_render's profile mode); `cpu_baseline` times the CPU oracle (kind "port": the faithful f64
+restatement with the platform libm; the Rust reference itself cannot be built here) on a bounded
+sample of the same workload, on rank 0 at N=1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0    # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s peak, ~6.3 achievable)
+# algorithmic bytes: f64 path record = 13 f64 + 3 u32 = 116 B
+B_EXTEND_PER_SEGMENT = 56 + 12           # ray in (7 f64) + hit out (t f64 + prim u32)
+B_SHADE_PER_SEGMENT = 116 + 12 + 116     # record in + hit in + record out
+B_FB_PER_SAMPLE = 24                     # 3 f64 accumulator add per finished sample
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", type=int, default=6)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--spp", type=int, default=4000)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--slots-per-pixel", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_id, width, seconds, images):
+    """Times the oracle (the CHECKER, here only as the reported CPU baseline — never the product
+    path) on all host cores: same scene, same resolution, as many spp as fit in ~`seconds`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as orc
+
+    orc.set_math_mode(False)                 # platform libm, like the Rust reference
+    s = orc.Scene()
+    cam = s.build_scene(scene_id, width, 1, images=images)     # BVH build is not timed (camera.rs:80 starts after it)
+    h = orc.image_height(cam)
+    t = time.time()
+    s.render(cam, 1, 0, 1)
+    t1 = max(time.time() - t, 1e-3)
+    spp = int(max(1, min(64, round(seconds / t1))))
+    t = time.time()
+    _, cnt = s.render(cam, 1, 1, 1 + spp)
+    dt = time.time() - t
+    s.close()
+    cores = os.cpu_count()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cpu_name = ""
+    try:
+        cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": round(width * h * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"scene {scene_id} {width}x{h} @ {spp} spp ({dt:.1f} s of CPU work, OpenMP over pixels, libm math)",
+            "cpu": cpu_name, "segments_per_sample": round(cnt["segments"] / cnt["samples"], 4)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    import parallel_spp
+
+    pt = importlib.import_module("thu-acg-f2024-path-tracer_amd")
+    ctx = pt.Context(local_rank)                       # fails loudly without a GPU
+    scene = pt.Scene(ctx)
+    t0 = time.time()
+    cam = scene.build_scene(args.scene, args.width, args.spp)
+    build_s = time.time() - t0
+    height = pt.image_height(cam)
+    lo, hi = parallel_spp.shard_range(args.spp, rank, world)
+    n_pix = args.width * height
+    dev_accum = torch.zeros((height, args.width, 3), dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(profile):
+        acc, st = scene.render(cam, args.seed, lo, hi, slots_per_pixel=args.slots_per_pixel, profile=profile)
+        if world > 1:
+            dev_accum.copy_(torch.from_numpy(acc))
+            parallel_spp.reduce_accum_to_root(dev_accum)     # the single RCCL collective of the frame
+            torch.cuda.synchronize()
+        return acc, st
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t_start = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        acc, st = step(True)
+        stats.append(st.as_dict())
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        seg = torch.tensor([sum(s["segments"] for s in stats), sum(s["samples"] for s in stats)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(seg)
+        total_segments, total_samples = seg.tolist()
+    else:
+        total_segments = sum(s["segments"] for s in stats)
+        total_samples = sum(s["samples"] for s in stats)
+
+    if rank == 0:
+        samples_per_step = n_pix * args.spp
+        value = samples_per_step * args.steps / elapsed / 1e6
+        # dominant kernel on this rank, live HIP-event timing
+        ms_ext = sum(s["ms_extend"] for s in stats); ms_sh = sum(s["ms_shade"] for s in stats)
+        n_ext = sum(s["launches_extend"] for s in stats); n_sh = sum(s["launches_shade"] for s in stats)
+        my_seg = sum(s["segments"] for s in stats); my_smp = sum(s["samples"] for s in stats)
+        if ms_ext >= ms_sh:
+            kname, kms, kn = "k_extend", ms_ext, n_ext
+            bytes_total = my_seg * B_EXTEND_PER_SEGMENT
+        else:
+            kname, kms, kn = "k_shade", ms_sh, n_sh
+            bytes_total = my_seg * B_SHADE_PER_SEGMENT + my_smp * B_FB_PER_SAMPLE
+        avg_ms = kms / max(kn, 1)
+        achieved = (bytes_total / max(kn, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(kname, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel": kname,
+                    "avg_launch_ms": round(avg_ms, 5), "launches": int(kn),
+                    "algorithmic_bytes_per_launch": round(bytes_total / max(kn, 1), 1),
+                    "other_kernel": {"name": "k_shade" if kname == "k_extend" else "k_extend",
+                                     "avg_launch_ms": round((ms_sh if kname == "k_extend" else ms_ext) / max(n_sh if kname == "k_extend" else n_ext, 1), 5)},
+                    "whole_pipeline_GBps": round((my_seg * (B_EXTEND_PER_SEGMENT + B_SHADE_PER_SEGMENT) + my_smp * B_FB_PER_SAMPLE) / max((ms_ext + ms_sh) * 1e-3, 1e-9) / 1e9, 3)}
+        out = {
+            "metric": "Msamples/s (WxHxspp/s), scene 6 FHD@4000spp" if (args.scene, args.width, args.spp) == (6, 1920, 4000) else "Msamples/s (WxHxspp/s)",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"scene {args.scene} (reference main.rs scene script: bunny+spot+cow OBJ meshes, envmap) {args.width}x{height} @ {args.spp} spp, max_depth 50, seed {args.seed}",
+                       "parallelism": f"spp-sharded x{world}, one RCCL reduce of the f64 W*H*3 accumulator" if world > 1 else "single GPU",
+                       "slots_per_pixel": stats[0]["slots_per_pixel"], "resident_paths": stats[0]["n_slots"],
+                       "segments_per_sample": round(total_segments / max(total_samples, 1), 4), "scene_build_s": round(build_s, 3),
+                       "device": ctx.name()},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt._SCENE_IMAGES.get(args.scene, [])}
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.cpu_seconds, images)
+            out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

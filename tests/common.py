@@ -1,0 +1,142 @@
+"""Shared helpers for the tests: a backend-neutral scene description that is replayed onto
+the product API (GPU) and onto the oracle API (CPU), plus a small ulp metric."""
+from __future__ import annotations
+
+import numpy as np
+
+GOLDEN_DIR = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    ia = a.view(np.int64).copy()
+    ib = b.view(np.int64).copy()
+    ia[ia < 0] = np.int64(-(2**63)) - ia[ia < 0]
+    ib[ib < 0] = np.int64(-(2**63)) - ib[ib < 0]
+    with np.errstate(over="ignore"):
+        d = np.abs(ia - ib).astype(np.float64)      # exact in int64 (values of like sign / near zero)
+    d[np.isnan(a) & np.isnan(b)] = 0
+    return d
+
+
+class SceneSpec:
+    """Records builder calls; handles are indices into the call list's results."""
+
+    def __init__(self):
+        self.calls = []   # (method, args) where an arg wrapped in Ref(i) is the result of call i
+        self.camera = None
+
+    class Ref(int):
+        pass
+
+    def add(self, method, *args):
+        self.calls.append((method, args))
+        return SceneSpec.Ref(len(self.calls) - 1)
+
+    def replay(self, scene):
+        results = []
+        for method, args in self.calls:
+            real = [results[a] if isinstance(a, SceneSpec.Ref) else a for a in args]
+            results.append(scene.call(method, *real))
+        return results
+
+    def make_camera(self, cam_cls, results):
+        c = cam_cls()
+        for k, v in self.camera.items():
+            if k == "env_tex":
+                v = results[v] if isinstance(v, SceneSpec.Ref) else v
+            if isinstance(v, (tuple, list)):
+                for i, x in enumerate(v):
+                    getattr(c, k)[i] = x
+            else:
+                setattr(c, k, v)
+        return c
+
+
+def default_camera(width=48, aspect=1.0, spp=4, **kw):
+    cam = dict(aspect_ratio=aspect, image_width=width, samples_per_pixel=spp, max_depth=50, env_is_map=0, vfov=50.0,
+               look_from=(0.0, 1.0, -6.0), look_at=(0.0, 0.5, 0.0), vup=(0.0, 1.0, 0.0), blur_strength=0.5, focal_length=6.0,
+               defocus_angle=0.5, env_color=(0.6, 0.7, 0.9), env_tex=-1)
+    cam.update(kw)
+    return cam
+
+
+def icosphere(subdiv=1):
+    """Small closed triangle mesh (float32 positions, uint32 indices) for mesh tests."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, dtype=np.float32), np.array(f, dtype=np.uint32).reshape(-1)
+
+
+def random_scene(seed, with_mesh=True, with_lights=True, n_objects=10, sphere_light=False):
+    """A random but valid scene touching every primitive and material kind."""
+    rng = np.random.default_rng(seed)
+    s = SceneSpec()
+    U = lambda lo, hi: float(rng.uniform(lo, hi))
+    col = lambda: (U(0.05, 0.95), U(0.05, 0.95), U(0.05, 0.95))
+
+    def material():
+        k = int(rng.integers(0, 4))
+        tex = s.add("tex_solid_rgb", *col())
+        if rng.random() < 0.25:
+            tex = s.add("tex_checker", U(0.2, 1.5), tex, s.add("tex_solid_rgb", *col()))
+        if k == 0:
+            return s.add("mat_diffuse", tex, -1)
+        if k == 1:
+            return s.add("mat_metal", tex, s.add("tex_solid_f", U(0.0, 0.6)))
+        if k == 2:
+            return s.add("mat_glass", tex, s.add("tex_solid_f", U(0.001, 0.4)), 0.0, U(1.2, 1.8))
+        p = [U(0, 1), U(0.01, 0.8), U(0, 1), U(0, 1), U(0, 1), U(1.2, 1.8), U(0, 1), U(0, 1), U(0, 1), U(0, 1), U(0, 1)]
+        return s.add("mat_principled", tex, p)
+
+    ground = s.add("mat_diffuse", s.add("tex_checker", 0.7, s.add("tex_solid_rgb", 0.2, 0.3, 0.1), s.add("tex_solid_rgb", 0.9, 0.9, 0.9)), -1)
+    s.add("world_add_object", s.add("quad", (-20.0, 0.0, -20.0), (0.0, 0.0, 40.0), (40.0, 0.0, 0.0), ground))
+    for _ in range(n_objects):
+        kind = int(rng.integers(0, 5 if with_mesh else 4))
+        pos = (U(-3, 3), U(0.3, 2.0), U(-2, 4))
+        m = material()
+        if kind == 0:
+            obj = s.add("sphere", U(0.2, 0.8), pos, pos, m)
+        elif kind == 1:
+            p2 = (pos[0], pos[1] + U(0, 0.5), pos[2])
+            obj = s.add("sphere", U(0.2, 0.5), pos, p2, m)
+        elif kind == 2:
+            obj = s.add("quad", pos, (U(0.3, 1.5), U(-0.3, 0.3), 0.0), (0.0, U(0.3, 1.5), U(-0.3, 0.3)), m)
+        elif kind == 3:
+            box = s.add("cuboid", (0.0, 0.0, 0.0), (U(0.3, 1.0), U(0.3, 1.5), U(0.3, 1.0)), m)
+            obj = s.add("instance", box, (0.0, 1.0, 0.0), U(-1.0, 1.0), (pos[0], 0.0, pos[2]))
+        else:
+            P, I = icosphere(int(rng.integers(0, 3)))
+            mesh = s.add("mesh", U(0.3, 0.8), P, I, None, None, m)
+            axis = np.array([U(-1, 1), U(0.2, 1), U(-1, 1)]); axis /= np.linalg.norm(axis)
+            obj = s.add("instance", mesh, tuple(axis), U(-2, 2), pos)
+        s.add("world_add_object", obj)
+    if with_lights:
+        lm = s.add("mat_light", s.add("tex_solid_rgb", 8.0, 8.0, 7.0))
+        s.add("world_add_light", s.add("quad", (-1.0, 4.0, -1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), lm))
+        if sphere_light:   # NB: the reference's Sphere::pdf (sphere.rs:124-135) yields NaN/inf for origins ON the sphere
+            lm2 = s.add("mat_light", s.add("tex_solid_rgb", 5.0, 4.0, 3.0))
+            c = (U(-2, 2), 3.0, U(-1, 2))
+            s.add("world_add_light", s.add("sphere", 0.3, c, c, lm2))
+    s.add("world_build")
+    s.camera = default_camera(env_color=(0.6, 0.7, 0.9) if not with_lights else (0.05, 0.05, 0.08))
+    return s
