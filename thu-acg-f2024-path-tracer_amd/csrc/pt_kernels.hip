@@ -116,16 +116,26 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t seed) {
-    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_slots; s += gridDim.x * BLOCK) {
-        const uint32_t pixel = s % pool.n_pixels, sub = s / pool.n_pixels;
-        const uint32_t sample = pool.spp_begin + sub;
-        pool.ax[s] = 0.0; pool.ay[s] = 0.0; pool.az[s] = 0.0;
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
+        uint32_t pixel, sample;
+        bool has_work;
+        if (pool.dynamic) {   // initial work items 0 .. n_slots-1 (the host starts next_work there)
+            pixel = s % pool.n_pixels;
+            sample = pool.spp_begin + s / pool.n_pixels;
+            has_work = s < pool.n_slots && (unsigned long long)s < pool.total_work;
+            pool.pixel[s] = pixel;
+        } else {
+            pixel = s % pool.n_pixels;
+            sample = pool.spp_begin + s / pool.n_pixels;
+            has_work = s < pool.n_slots && sample < pool.spp_end;
+            pool.ax[s] = 0.0; pool.ay[s] = 0.0; pool.az[s] = 0.0;
+        }
         pool.rx[s] = 0.0; pool.ry[s] = 0.0; pool.rz[s] = 0.0;
         pool.tx[s] = 1.0; pool.ty[s] = 1.0; pool.tz[s] = 1.0;
         pool.sample[s] = sample;
         pool.hit_prim[s] = HIT_NONE;
         pool.hit_t[s] = D_INF;
-        if (sample >= pool.spp_end) {
+        if (!has_work) {
             pool.bounce[s] = SLOT_DEAD;
             pool.draw[s] = 0;
             continue;
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
 __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     unsigned long long nseg = 0;
-    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_slots; s += gridDim.x * BLOCK) {
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
         if (pool.bounce[s] == SLOT_DEAD) continue;
         RayD r{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
         Closest c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
@@ -156,81 +166,119 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     unsigned long long n_done = 0, n_died = 0;
-    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_slots; s += gridDim.x * BLOCK) {
+    // n_alloc is a multiple of 64 and the stride a multiple of 256, so whole waves enter or skip an
+    // iteration together: the wave-level ballot below sees all 64 lanes.
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
         uint32_t bounce = pool.bounce[s];
-        if (bounce == SLOT_DEAD) continue;
-        const uint32_t pixel = s % pool.n_pixels;
-        RayD ray{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
-        V3 thr{pool.tx[s], pool.ty[s], pool.tz[s]};
-        V3 rad{pool.rx[s], pool.ry[s], pool.rz[s]};
-        Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, pool.sample[s], pool.draw[s]};
-        const uint32_t gid = pool.hit_prim[s];
+        const bool alive = bounce != SLOT_DEAD;
         bool finished = false;
-        HitD hit;
-        if (gid == HIT_NONE || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
-            rad = rad + thr * sample_environment(sc, cam, ray.d);   // camera.rs:180-183
-            finished = true;
-        } else {
-            const MatD& m = sc.mats[hit.mat];
-            // camera.rs:186-187 — added for every material (zero unless emissive) so that a
-            // non-finite throughput poisons the sample exactly as it does in the reference
-            V3 emission = m.kind == MAT_LIGHT ? tex_rgb(sc, m.color_tex, hit.u, hit.v, hit.point) : V3{0.0, 0.0, 0.0};
-            rad = rad + thr * emission;
-            if (bounce > 5) {                                        // russian roulette :190-196
-                double p = clampd(luminance(thr), 0.01, 1.0);
-                if (rng_f64(rng) > p) finished = true;
-                else thr = thr / p;
-            }
-            if (!finished) {
-                const double p_light = sc.n_lights == 0 ? 0.0 : 0.5;   // :199-200
-                const double p_bsdf = 1.0 - p_light;
-                const V3 wo = -ray.d;
-                double rsel = rng_f64(rng);
-                V3 dir;
-                bool ok = true;
-                if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
-                else ok = mat_sample(sc, m, hit, wo, rng, cam.two_pi_scale, dir);
-                if (!ok) {
-                    finished = true;                                 // :209-211
-                } else {
-                    double bsdf_pdf;
-                    V3 brdf;
-                    mat_pdf_eval(sc, m, hit, wo, dir, bsdf_pdf, brdf);
-                    double light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
-                    double pdf = p_bsdf * bsdf_pdf + p_light * light_pdf;
-                    V3 attenuation = brdf / pdf;
-                    double e = 1e-3 * signum(dot(dir, hit.gn));      // :217-222
-                    ray = make_ray(hit.point + e * hit.gn, dir, ray.time);
-                    thr = thr * attenuation;
-                    ++bounce;
-                    if (bounce >= cam.max_depth) finished = true;    // loop bound :177
+        uint32_t pixel = 0;
+        RayD ray{};
+        V3 thr{}, rad{};
+        Rng rng{};
+        if (alive) {
+            pixel = pool.dynamic ? pool.pixel[s] : s % pool.n_pixels;
+            ray = RayD{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
+            thr = V3{pool.tx[s], pool.ty[s], pool.tz[s]};
+            rad = V3{pool.rx[s], pool.ry[s], pool.rz[s]};
+            rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, pool.sample[s], pool.draw[s]};
+            const uint32_t gid = pool.hit_prim[s];
+            HitD hit;
+            if (gid == HIT_NONE || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
+                rad = rad + thr * sample_environment(sc, cam, ray.d);   // camera.rs:180-183
+                finished = true;
+            } else {
+                const MatD& m = sc.mats[hit.mat];
+                // camera.rs:186-187 — added for every material (zero unless emissive) so that a
+                // non-finite throughput poisons the sample exactly as it does in the reference
+                V3 emission = m.kind == MAT_LIGHT ? tex_rgb(sc, m.color_tex, hit.u, hit.v, hit.point) : V3{0.0, 0.0, 0.0};
+                rad = rad + thr * emission;
+                if (bounce > 5) {                                        // russian roulette :190-196
+                    double p = clampd(luminance(thr), 0.01, 1.0);
+                    if (rng_f64(rng) > p) finished = true;
+                    else thr = thr / p;
+                }
+                if (!finished) {
+                    const double p_light = sc.n_lights == 0 ? 0.0 : 0.5;   // :199-200
+                    const double p_bsdf = 1.0 - p_light;
+                    const V3 wo = -ray.d;
+                    double rsel = rng_f64(rng);
+                    V3 dir;
+                    bool ok = true;
+                    if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
+                    else ok = mat_sample(sc, m, hit, wo, rng, cam.two_pi_scale, dir);
+                    if (!ok) {
+                        finished = true;                                 // :209-211
+                    } else {
+                        double bsdf_pdf;
+                        V3 brdf;
+                        mat_pdf_eval(sc, m, hit, wo, dir, bsdf_pdf, brdf);
+                        double light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
+                        double pdf = p_bsdf * bsdf_pdf + p_light * light_pdf;
+                        V3 attenuation = brdf / pdf;
+                        double e = 1e-3 * signum(dot(dir, hit.gn));      // :217-222
+                        ray = make_ray(hit.point + e * hit.gn, dir, ray.time);
+                        thr = thr * attenuation;
+                        ++bounce;
+                        if (bounce >= cam.max_depth) finished = true;    // loop bound :177
+                    }
                 }
             }
         }
-        if (finished) {
-            pool.ax[s] += rad.x; pool.ay[s] += rad.y; pool.az[s] += rad.z;   // camera.rs:107
+        // ---- finished paths: accumulate (camera.rs:107) and regenerate in place -----------------
+        uint32_t next_pixel = pixel, next_sample = 0;
+        bool more = false;
+        if (pool.dynamic) {
+            // K5: wave ballot + prefix popcount, ONE atomic per wave on the global work counter
+            const unsigned long long mask = __ballot(alive && finished);
+            if (mask) {
+                const int lane = (int)(threadIdx.x & 63u);
+                const int leader = __ffsll((long long)mask) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(&cnt->next_work, (unsigned long long)__popcll(mask));
+                base = __shfl(base, leader);
+                if (alive && finished) {
+                    const unsigned long long w = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], rad.x);
+                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], rad.y);
+                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], rad.z);
+                    if (w < pool.total_work) {
+                        more = true;
+                        next_pixel = (uint32_t)(w % pool.n_pixels);
+                        next_sample = pool.spp_begin + (uint32_t)(w / pool.n_pixels);
+                    }
+                }
+            }
+        } else if (alive && finished) {
+            pool.ax[s] += rad.x; pool.ay[s] += rad.y; pool.az[s] += rad.z;
+            next_sample = pool.sample[s] + pool.k;
+            more = next_sample < pool.spp_end;
+        }
+        if (alive && finished) {
             ++n_done;
-            const uint32_t next = pool.sample[s] + pool.k;
-            if (next < pool.spp_end) {
-                rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, next, 0u};
-                ray = generate_ray(cam, pixel / cam.width, pixel % cam.width, rng);
+            if (more) {
+                rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), next_pixel, next_sample, 0u};
+                ray = generate_ray(cam, next_pixel / cam.width, next_pixel % cam.width, rng);
                 thr = V3{1.0, 1.0, 1.0};
                 rad = V3{0.0, 0.0, 0.0};
                 bounce = 0;
-                pool.sample[s] = next;
+                pool.sample[s] = next_sample;
+                if (pool.dynamic) pool.pixel[s] = next_pixel;
             } else {
                 bounce = SLOT_DEAD;
                 ++n_died;
             }
         }
-        pool.bounce[s] = bounce;
-        if (bounce != SLOT_DEAD) {
-            pool.ox[s] = ray.o.x; pool.oy[s] = ray.o.y; pool.oz[s] = ray.o.z;
-            pool.dx[s] = ray.d.x; pool.dy[s] = ray.d.y; pool.dz[s] = ray.d.z;
-            pool.time[s] = ray.time;
-            pool.tx[s] = thr.x; pool.ty[s] = thr.y; pool.tz[s] = thr.z;
-            pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z;
-            pool.draw[s] = rng.draw;
+        if (alive) {
+            pool.bounce[s] = bounce;
+            if (bounce != SLOT_DEAD) {
+                pool.ox[s] = ray.o.x; pool.oy[s] = ray.o.y; pool.oz[s] = ray.o.z;
+                pool.dx[s] = ray.d.x; pool.dy[s] = ray.d.y; pool.dz[s] = ray.d.z;
+                pool.time[s] = ray.time;
+                pool.tx[s] = thr.x; pool.ty[s] = thr.y; pool.tz[s] = thr.z;
+                pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z;
+                pool.draw[s] = rng.draw;
+            }
         }
     }
     if (n_done) atomicAdd(&cnt->samples, n_done);
@@ -318,14 +366,14 @@ static inline dim3 grid_for(uint32_t n, int max_blocks) {
     return dim3(b);
 }
 void launch_init(const CamD& cam, const PoolD& pool, uint64_t seed, int max_blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_init, grid_for(pool.n_slots, max_blocks), dim3(BLOCK), 0, st, cam, pool, seed);
+    hipLaunchKernelGGL(k_init, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, cam, pool, seed);
 }
 void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_extend, grid_for(pool.n_slots, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    hipLaunchKernelGGL(k_extend, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
 }
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks,
                   hipStream_t st) {
-    hipLaunchKernelGGL(k_shade, grid_for(pool.n_slots, max_blocks), dim3(BLOCK), 0, st, sc, cam, pool, cnt, seed);
+    hipLaunchKernelGGL(k_shade, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, cam, pool, cnt, seed);
 }
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);

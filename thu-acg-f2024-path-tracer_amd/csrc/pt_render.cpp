@@ -3,6 +3,7 @@
 // stream, poll the live-slot counter every few iterations, report per-kernel HIP-event times.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -192,24 +193,30 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const uint32_t n_pixels = (uint32_t)n_pixels64;
     const uint32_t spp = spp_end - spp_begin;
 
-    // pool sizing: k slots per pixel. Auto: enough resident paths to fill the machine several
-    // times over (occupancy + tail balance), capped by the sample count and by memory.
+    // pool sizing. slots_per_pixel = 0 (default): DYNAMIC work assignment — a fixed pool that fills
+    // the machine several times over; finished paths pull the next (pixel, sample) from a global
+    // counter. slots_per_pixel = k >= 1: STATIC ownership (deterministic; k = 1 is the reference's
+    // exact per-pixel sample order).
     uint32_t k = opts.slots_per_pixel;
-    if (k == 0) {
-        const uint64_t target = (uint64_t)ctx->n_cus * 16384ull;   // ~4M paths on 256 CUs
-        k = (uint32_t)((target + n_pixels - 1) / n_pixels);
-        if (const char* e = getenv("PT_SLOTS_PER_PIXEL")) k = (uint32_t)atoi(e);
+    if (const char* e = getenv("PT_SLOTS_PER_PIXEL")) k = (uint32_t)atoi(e);
+    const bool dynamic = k == 0;
+    const uint64_t total_work = (uint64_t)n_pixels * spp;
+    uint64_t n_slots64;
+    if (dynamic) {
+        uint64_t target = (uint64_t)ctx->n_cus * 16384ull;   // ~4M resident paths on 256 CUs
+        if (const char* e = getenv("PT_POOL_SLOTS")) target = strtoull(e, nullptr, 10);
+        n_slots64 = std::min<uint64_t>(target, std::max<uint64_t>(total_work, 1));
+    } else {
+        if (k > spp) k = spp;
+        if (k == 0) k = 1;
+        while ((uint64_t)k * n_pixels > 0x40000000ull && k > 1) --k;
+        n_slots64 = (uint64_t)k * n_pixels;
     }
-    if (k > spp) k = spp;
-    if (k == 0) k = 1;
-    while ((uint64_t)k * n_pixels > 0x40000000ull && k > 1) --k;
-    const uint64_t n_slots64 = (uint64_t)k * n_pixels;
-    if (n_slots64 > 0x7FFFFFFFull) return set_error("pt_render: image too large for the path pool");
+    if (n_slots64 > 0x7FFFFFC0ull) return set_error("pt_render: image too large for the path pool");
     const uint32_t n_slots = (uint32_t)n_slots64;
-
-    // one allocation, carved into the SoA arrays (17 f64 + 4 u32 per slot)
+    // one allocation, carved into the SoA arrays (17 f64 + 5 u32 per slot)
     const size_t n_al = ((size_t)n_slots + 63) & ~(size_t)63;
-    const size_t bytes = n_al * (17 * sizeof(double) + 4 * sizeof(uint32_t));
+    const size_t bytes = n_al * (17 * sizeof(double) + 5 * sizeof(uint32_t));
     if (bytes > s->pool_bytes) {
         if (s->pool_mem) (void)hipFree(s->pool_mem);
         s->pool_mem = nullptr;
@@ -229,14 +236,17 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
                              &pool.tz, &pool.rx, &pool.ry, &pool.rz, &pool.ax, &pool.ay, &pool.az, &pool.hit_t};
         for (auto p : f64s) { *p = d; d += n_al; }
         uint32_t* u = (uint32_t*)d;
-        uint32_t** u32s[4] = {&pool.hit_prim, &pool.sample, &pool.bounce, &pool.draw};
+        uint32_t** u32s[5] = {&pool.hit_prim, &pool.sample, &pool.bounce, &pool.draw, &pool.pixel};
         for (auto p : u32s) { *p = u; u += n_al; }
     }
     pool.n_slots = n_slots;
+    pool.n_alloc = (uint32_t)n_al;
     pool.n_pixels = n_pixels;
-    pool.k = k;
+    pool.k = dynamic ? 0u : k;
     pool.spp_begin = spp_begin;
     pool.spp_end = spp_end;
+    pool.dynamic = dynamic ? 1u : 0u;
+    pool.total_work = total_work;
 
     // accumulator on the device
     double* d_accum = accum;
@@ -252,9 +262,11 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const int blocks_extend = kernel_occupancy_blocks(0), blocks_shade = kernel_occupancy_blocks(1);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
+    pool.accum = d_accum;
     CountersD init_cnt;
     memset(&init_cnt, 0, sizeof init_cnt);
-    init_cnt.alive = spp == 0 ? 0 : n_slots;   // k <= spp, so every slot has at least one sample
+    init_cnt.alive = spp == 0 ? 0 : n_slots;   // every slot starts with one sample (k <= spp / n_slots <= total_work)
+    init_cnt.next_work = n_slots;              // dynamic mode: items 0 .. n_slots-1 are handed out by k_init
     if (!hip_ok(hipMemcpyAsync(s->d_counters, &init_cnt, sizeof init_cnt, hipMemcpyHostToDevice, st), "hipMemcpy(counters)")) return -1;
 
     EventTimer timer;
@@ -267,7 +279,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     launch_init(dc, pool, seed, grid_shade, st);
     timer.end(st);
     uint64_t iterations = 0;
-    const uint64_t per_slot = (spp + k - 1) / k;
+    const uint64_t per_slot = dynamic ? (total_work + n_slots - 1) / std::max<uint64_t>(n_slots, 1) + 1 : (spp + k - 1) / k;
     const uint64_t max_iterations = per_slot * (uint64_t)std::max(1u, dc.max_depth) + 4;
     uint32_t poll_every = 8;
     bool alive = spp != 0 && dc.max_depth != 0;
@@ -292,9 +304,11 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (alive && iterations > max_iterations + 128) return set_error("pt_render: iteration bound exceeded (internal error)");
         if (poll_every < 64) poll_every *= 2;
     }
-    timer.begin(2, st);
-    launch_resolve(pool, d_accum, ctx->n_cus * 8, st);
-    timer.end(st);
+    if (!dynamic) {
+        timer.begin(2, st);
+        launch_resolve(pool, d_accum, ctx->n_cus * 8, st);
+        timer.end(st);
+    }
     if (!hip_ok(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(CountersD), hipMemcpyDeviceToHost, st), "hipMemcpy(counters)")) return -1;
     if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(resolve)")) return -1;
     timer.drain();
@@ -314,7 +328,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         stats->segments = s->h_counters->segments;
         stats->iterations = iterations;
         stats->n_slots = n_slots;
-        stats->slots_per_pixel = k;
+        stats->slots_per_pixel = dynamic ? 0u : k;
         stats->ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
         stats->ms_extend = timer.ms[0];
         stats->ms_shade = timer.ms[1];

@@ -103,7 +103,15 @@ struct SceneD {
 };
 
 // ---- path pool (SoA, one slot per resident path) ---------------------------------------
-// Slot s owns pixel (s % n_pixels) and renders samples spp_begin + (s / n_pixels) + j*k.
+// Two work-assignment modes:
+//  static  (slots_per_pixel = k >= 1): slot s owns pixel (s % n_pixels) and renders samples
+//          spp_begin + (s / n_pixels) + j*k into its own accumulator ax/ay/az; deterministic, and
+//          for k = 1 exactly the reference's per-pixel sample order (camera.rs:106-108).
+//  dynamic (default): a finished path pulls the next (pixel, sample) work item from one global
+//          counter — wave-aggregated: ballot + popcount + one atomic per wave — so every lane
+//          stays busy until the frame's sample budget is exhausted; radiance is added to the
+//          frame accumulator with hardware f64 atomics. Work item i -> pixel i % n_pixels,
+//          sample spp_begin + i / n_pixels (neighbouring lanes start on neighbouring pixels).
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 constexpr uint32_t SLOT_DEAD = 0xFFFFFFFFu;   // value of `bounce` for a finished slot
 struct PoolD {
@@ -114,15 +122,19 @@ struct PoolD {
     double* hit_t;
     uint32_t* hit_prim;
     uint32_t *sample, *bounce, *draw;
-    uint32_t n_slots, n_pixels, k;                // k = slots per pixel
+    uint32_t* pixel;                              // dynamic mode: pixel of the sample in flight
+    double* accum;                                // dynamic mode: frame accumulator (W*H*3 sums)
+    unsigned long long total_work;                // dynamic mode: n_pixels * (spp_end - spp_begin)
+    uint32_t n_slots, n_pixels, k;                // k = slots per pixel (static mode)
     uint32_t spp_begin, spp_end;
+    uint32_t dynamic, n_alloc;                    // n_alloc: slots rounded up to a multiple of 64
 };
 
 struct CountersD {
     unsigned long long alive;        // slots still rendering
     unsigned long long segments;     // extend() calls on live paths
     unsigned long long samples;      // finished samples
-    unsigned long long pad;
+    unsigned long long next_work;    // dynamic mode: next unassigned work item
 };
 
 }  // namespace pt
