@@ -80,6 +80,29 @@ def test_closest_hit_bit_exact(pt, det, ctx, scene_images, sid):
     gs.close(); os_.close()
 
 
+def test_axis_parallel_rays(pt, det, ctx, scene_images):
+    """Directions with exactly-zero components (1/d = inf in the slab test) from origins inside
+    the room: they occur in real renders (a direction sampled inside the plane of the axis-aligned
+    Cornell light) and once made a NaN-ignoring min/max drop a whole subtree."""
+    gs, gcam, os_, ocam = _pair(pt, det, ctx, scene_images, 3, 64, 1)
+    rng = np.random.default_rng(2)
+    n = 3000
+    rays = np.zeros((n, 7))
+    rays[:, 0:3] = rng.uniform(5, 550, (n, 3))
+    d = rng.normal(size=(n, 3))
+    zero = rng.integers(0, 3, n)
+    d[np.arange(n), zero] = 0.0
+    d[: n // 3, (zero[: n // 3] + 1) % 3] = 0.0           # a third of them parallel to an axis
+    d[n - 100:, :] *= -1.0
+    d[n - 50:, zero[n - 50:]] = -0.0
+    rays[:, 3:6] = d
+    rays[: n // 6, 1] = 554.0                             # origins exactly in the light's plane
+    g = gs.intersect(rays)
+    assert (g[:, 0] == 1).mean() > 0.5        # the room is open towards the camera
+    np.testing.assert_array_equal(g, os_.intersect(rays))
+    gs.close(); os_.close()
+
+
 def test_tie_rule_and_coplanar_quads(pt, det, ctx):
     def build(s):
         m1 = s.mat_diffuse(s.tex_solid_rgb(1, 0, 0)); m2 = s.mat_diffuse(s.tex_solid_rgb(0, 1, 0)); l = s.mat_light(s.tex_solid_rgb(5, 5, 5))

@@ -43,6 +43,28 @@ PT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv, double t_min, d
     t_near = tn;
     return tn <= tf;
 }
+// 1/d for the fma slab test, clamped to a finite magnitude: with d == 0 (exactly axis-parallel
+// rays DO occur: a direction sampled inside the plane of an axis-aligned light) 1/d = inf would
+// turn lo*inv - o*inv into inf - inf = NaN and a NaN-ignoring min/max then drops the wrong end of
+// the slab interval. With |inv| <= 1e290 every product stays finite and the axis behaves like
+// "parallel": (-huge, +huge) when the origin is inside the slab, empty when it is outside.
+PT_DEV double safe_inv(double d) {
+    double i = 1.0 / d;
+    if (!(fabs(i) <= 1e290)) i = __builtin_copysign(1e290, d);
+    return i;
+}
+PT_DEV V3 safe_inv3(V3 d) { return V3{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)}; }
+PT_DEV bool slab_fma(const float* lo, const float* hi, V3 inv, V3 oi, double t_min, double t_max, double& t_near) {
+    double t1x = __builtin_fma((double)lo[0], inv.x, -oi.x), t2x = __builtin_fma((double)hi[0], inv.x, -oi.x);
+    double t1y = __builtin_fma((double)lo[1], inv.y, -oi.y), t2y = __builtin_fma((double)hi[1], inv.y, -oi.y);
+    double t1z = __builtin_fma((double)lo[2], inv.z, -oi.z), t2z = __builtin_fma((double)hi[2], inv.z, -oi.z);
+    double tn = fmax(fmax(fmin(t1x, t2x), fmin(t1y, t2y)), fmax(fmin(t1z, t2z), t_min));
+    double tf = fmin(fmin(fmax(t1x, t2x), fmax(t1y, t2y)), fmin(fmax(t1z, t2z), t_max));
+    t_near = tn;
+    return tn <= tf;
+}
+
+
 PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint32_t gid, Closest& best) {
     const PrimRef pr = sc.prims[gid];
     if ((pr.kind & 0xFFu) == PRIM_SPHERE) {
@@ -55,6 +77,7 @@ PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint3
     }
 }
 
+template <bool FMA>
 PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uint32_t* stk /* &stack[0][lane] */) {
     Closest best{D_INF, HIT_NONE};
     RayD r = wray;
@@ -70,8 +93,9 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
             const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
             const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
             double tn0, tn1;
-            bool h0 = slab(lo0, hi0, r.o, inv, t_min, best.t, tn0);
-            bool h1 = slab(lo1, hi1, r.o, inv, t_min, best.t, tn1);
+            const V3 sinv = safe_inv3(r.d), oi = r.o * sinv;
+            bool h0 = FMA ? slab_fma(lo0, hi0, sinv, oi, t_min, best.t, tn0) : slab(lo0, hi0, r.o, inv, t_min, best.t, tn0);
+            bool h1 = FMA ? slab_fma(lo1, hi1, sinv, oi, t_min, best.t, tn1) : slab(lo1, hi1, r.o, inv, t_min, best.t, tn1);
             uint32_t c0 = q3.x, c1 = q3.y;
             if (h0 && h1) {
                 if (tn1 < tn0) {
@@ -150,13 +174,16 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
     }
 }
 
+// K2, batch form: a fixed grid walks the pool with a grid-stride loop; each lane traverses one ray
+// at a time, a wave moves on when its slowest lane is done. Lowest overhead; SIMD utilisation
+// suffers when traversal lengths inside a wave differ a lot (sky ray next to a mesh ray).
 __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     unsigned long long nseg = 0;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
         if (pool.bounce[s] == SLOT_DEAD) continue;
         RayD r{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
-        Closest c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
+        Closest c = closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
         pool.hit_t[s] = c.t;
         pool.hit_prim[s] = c.id;
         ++nseg;
@@ -164,8 +191,124 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
     if (nseg) atomicAdd(&cnt->segments, nseg);
 }
 
+// K2 as a persistent-thread kernel with DYNAMIC RAY FETCH (Aila-Laine style): traversal lengths
+// vary by two orders of magnitude between a sky ray and a ray grazing a mesh, so a lane that
+// finishes its ray does not wait for the slowest lane of its wave — whenever enough lanes of the
+// wave are idle, the idle lanes pull the next slots from a per-launch cursor (ballot + popcount +
+// one atomic per wave) and start traversing them while the others continue. Each loop iteration
+// performs ONE traversal step (node visit / triangle leaf / world entry / pop) per active lane.
+// Box tests use t = fma(b, 1/d, -o/d): they only have to be conservative (boxes are padded), the
+// primitive tests that decide the result keep the reference's exact arithmetic.
+__global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, CountersD* cnt, int fetch_threshold) {
+    __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
+    uint32_t* stk = &stack[threadIdx.x];
+    const int lane = (int)(threadIdx.x & 63u);
+    const double t_min = 1e-3;                                    // camera.rs:171,179
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->shade_cursor = 0;   // for the k_shade that follows
+
+    bool active = false, exhausted = false;
+    uint32_t slot = 0, cur = 0;
+    int sp = 0;
+    RayD r{};          // ray in the current space (world, or instance-local inside a mesh)
+    V3 inv{}, oi{};    // 1/d and o/d of r
+    Closest best{D_INF, HIT_NONE};
+    unsigned long long nseg = 0;
+
+    for (;;) {
+        // ---- refill idle lanes ---------------------------------------------------------------
+        const unsigned long long idle = __ballot(!active);
+        if (!exhausted && (idle == ~0ull || __popcll(idle) >= fetch_threshold)) {
+            const int leader = __ffsll((long long)idle) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&cnt->extend_cursor, (unsigned long long)__popcll(idle));
+            base = __shfl(base, leader);
+            if (base >= pool.n_alloc) exhausted = true;           // wave-uniform
+            if (!active) {
+                const unsigned long long idx = base + (unsigned long long)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < pool.n_alloc && pool.bounce[idx] != SLOT_DEAD) {
+                    slot = (uint32_t)idx;
+                    r = RayD{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, pool.time[slot]};
+                    inv = safe_inv3(r.d);
+                    oi = r.o * inv;
+                    best = Closest{D_INF, HIT_NONE};
+                    sp = 0;
+                    cur = sc.tlas_root;
+                    active = true;
+                    ++nseg;
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (!active) continue;
+        // ---- one traversal step ----------------------------------------------------------------
+        bool pop = true;
+        if ((cur & REF_TYPE_MASK) == REF_NODE) {
+            const BvhNode* nd = &sc.nodes[cur];
+            const float4 q0 = ((const float4*)nd)[0], q1 = ((const float4*)nd)[1], q2 = ((const float4*)nd)[2];
+            const uint4 q3 = ((const uint4*)nd)[3];
+            const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+            const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+            double tn0, tn1;
+            const bool h0 = slab_fma(lo0, hi0, inv, oi, t_min, best.t, tn0);
+            const bool h1 = slab_fma(lo1, hi1, inv, oi, t_min, best.t, tn1);
+            uint32_t c0 = q3.x, c1 = q3.y;
+            if (h0 && h1) {
+                if (tn1 < tn0) { const uint32_t tmp = c0; c0 = c1; c1 = tmp; }
+                if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = c1;
+                cur = c0;
+                pop = false;
+            } else if (h0) {
+                cur = c0;
+                pop = false;
+            } else if (h1) {
+                cur = c1;
+                pop = false;
+            }
+        } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
+            const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
+            for (uint32_t i = first; i < first + count; ++i) {
+                double t, u, v;
+                if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
+            }
+        } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
+            const Entry e = sc.entries[cur & 0x3FFFFFFFu];
+            RayD lr = r;                                          // world space here (entries live in the TLAS)
+            if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
+            if (e.kind == ENTRY_MESH) {
+                r = lr;
+                inv = safe_inv3(r.d);
+                oi = r.o * inv;
+                if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = REF_LEAVE_INSTANCE;
+                cur = e.blas_root;
+                pop = false;
+            } else {
+                const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
+                for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+            }
+        } else if (cur == REF_LEAVE_INSTANCE) {                   // back to world space: reload the ray
+            r = RayD{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, r.time};
+            inv = safe_inv3(r.d);
+            oi = r.o * inv;
+        }
+        if (pop) {
+            if (sp == 0) {
+                pool.hit_t[slot] = best.t;
+                pool.hit_prim[slot] = best.id;
+                active = false;
+            } else {
+                cur = stk[(--sp) * BLOCK];
+            }
+        }
+    }
+    if (nseg) atomicAdd(&cnt->segments, nseg);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     unsigned long long n_done = 0, n_died = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->extend_cursor = 0;   // for the k_extend that follows
     // n_alloc is a multiple of 64 and the stride a multiple of 256, so whole waves enter or skip an
     // iteration together: the wave-level ballot below sees all 64 lanes.
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
@@ -313,12 +456,12 @@ __global__ __launch_bounds__(BLOCK) void k_quantise(const double* accum, uint32_
 
 // Debug/parity probe: closest hit + reconstructed HitInfo for a batch of arbitrary rays.
 // out[15*i..] = {hit, t, prim_id, u, v, front, p.xyz, gn.xyz, sn.xyz}
-__global__ __launch_bounds__(BLOCK) void k_probe(SceneD sc, const double* rays /* o.xyz d.xyz time */, uint32_t n, double* out) {
+__global__ __launch_bounds__(BLOCK) void k_probe(SceneD sc, const double* rays /* o.xyz d.xyz time */, uint32_t n, double* out, int variant) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const double* q = rays + 7 * (size_t)i;
         RayD r = make_ray(V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, q[6]);
-        Closest c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);
+        Closest c = variant ? closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]) : closest_hit<false>(sc, r, 1e-3, &stack[threadIdx.x]);
         double* o = out + 15 * (size_t)i;
         for (int j = 0; j < 15; ++j) o[j] = 0.0;
         HitD h;
@@ -368,8 +511,9 @@ static inline dim3 grid_for(uint32_t n, int max_blocks) {
 void launch_init(const CamD& cam, const PoolD& pool, uint64_t seed, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_init, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, cam, pool, seed);
 }
-void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_extend, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int fetch_threshold, hipStream_t st) {
+    if (fetch_threshold <= 0) hipLaunchKernelGGL(k_extend, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    else hipLaunchKernelGGL(k_extend_fetch, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt, fetch_threshold);
 }
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks,
                   hipStream_t st) {
@@ -381,8 +525,8 @@ void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_
 void launch_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8, hipStream_t st) {
     hipLaunchKernelGGL(k_quantise, grid_for(n, 4096), dim3(BLOCK), 0, st, accum, n, scale, rgb8);
 }
-void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, sc, rays, n, out);
+void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, int variant, hipStream_t st) {
+    hipLaunchKernelGGL(k_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, sc, rays, n, out, variant);
 }
 void launch_math_probe(int which, const double* in, uint32_t n, double* out, hipStream_t st) {
     hipLaunchKernelGGL(k_math_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, which, in, n, out);

@@ -263,6 +263,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;
+    // K2 variant: 0 = batch kernel (default); n in 1..64 = persistent dynamic-fetch kernel that
+    // refills a wave when >= n of its 64 lanes are idle (experimental)
+    int fetch_threshold = 0;
+    if (const char* e = getenv("PT_FETCH_THRESHOLD")) fetch_threshold = std::min(64, std::max(0, atoi(e)));
     CountersD init_cnt;
     memset(&init_cnt, 0, sizeof init_cnt);
     init_cnt.alive = spp == 0 ? 0 : n_slots;   // every slot starts with one sample (k <= spp / n_slots <= total_work)
@@ -290,7 +294,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     while (alive) {
         for (uint32_t i = 0; i < poll_every; ++i) {
             timer.begin(0, st);
-            launch_extend(s->dev.view, pool, s->d_counters, grid_extend, st);
+            launch_extend(s->dev.view, pool, s->d_counters, grid_extend, fetch_threshold, st);
             timer.end(st);
             timer.begin(1, st);
             launch_shade(s->dev.view, dc, pool, s->d_counters, seed, grid_shade, st);
@@ -368,7 +372,7 @@ extern "C" int pt_intersect(pt_scene* s, const double* rays, uint32_t n, double*
               hip_ok(hipMalloc((void**)&d_o, (size_t)n * 15 * sizeof(double) + 8), "hipMalloc") &&
               hip_ok(hipMemcpyAsync(d_r, rays, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpy");
     if (ok) {
-        launch_probe(s->dev.view, d_r, n, d_o, ctx->stream);
+        launch_probe(s->dev.view, d_r, n, d_o, getenv("PT_PROBE_VARIANT") ? atoi(getenv("PT_PROBE_VARIANT")) : 1 /* fma slab test, like k_extend */, ctx->stream);
         ok = hip_ok(hipMemcpyAsync(out, d_o, (size_t)n * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy") &&
              hip_ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     }

@@ -135,6 +135,8 @@ struct CountersD {
     unsigned long long segments;     // extend() calls on live paths
     unsigned long long samples;      // finished samples
     unsigned long long next_work;    // dynamic mode: next unassigned work item
+    unsigned long long extend_cursor;   // per-launch slot cursor of k_extend's dynamic ray fetch (reset by k_shade)
+    unsigned long long shade_cursor;    // per-launch cursor of k_shade (reset by k_extend)
 };
 
 }  // namespace pt
