@@ -34,7 +34,49 @@ PT_DEV void consider(Closest& best, double t, uint32_t id) {
         best.id = id;
     }
 }
-PT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv, double t_min, double t_max, double& t_near) {
+// ---- conservative f32 slab test -----------------------------------------------------------------
+// Per ray and per space (world / instance-local) the f64 ray is reduced to idf = fl32(1/d),
+// oif = fl32(o/d) and t' = fma32(b, idf, -oif) for a box bound b. Error analysis (u = 2^-24):
+//   t' = (b*id*(1+da) - oi*(1+db))*(1+dc)  =>  |t' - t| <= 2u (|b||id| + |oi|) <= 2u (S|id| + |oi|)
+// with S = max |coordinate| of the boxes of the tree being walked (SceneD::tlas_extent /
+// Entry::extent). Every axis interval is widened by e = 4u (S|id| + |oi|) — twice the bound, which
+// also covers the rounding of e itself and of the +-e — so a box the exact ray touches inside
+// [t_min, t_best] is never rejected. 1/d is clamped to +-1e30 so that an exactly axis-parallel ray
+// (they occur: a direction sampled inside the plane of an axis-aligned light has d.y == 0) yields
+// finite products: the axis then behaves as "parallel" — everything when the origin is inside the
+// slab, nothing when it is outside. Box tests never influence WHICH hit wins, only how much work
+// it takes to find it; the primitive tests keep the reference's f64 arithmetic.
+struct RayF {
+    float idx, idy, idz, oix, oiy, oiz, ex, ey, ez;
+};
+PT_DEV void rayf_axis(double o, double d, float S, float& idf, float& oif, float& e) {
+    double id = 1.0 / d;
+    if (!(fabs(id) <= 1e30)) id = __builtin_copysign(1e30, d);
+    idf = (float)id;
+    oif = (float)(o * id);
+    e = (S * fabsf(idf) + fabsf(oif)) * 2.3841858e-07f;   // 4u
+}
+PT_DEV RayF make_rayf(V3 o, V3 d, float S) {
+    RayF f;
+    rayf_axis(o.x, d.x, S, f.idx, f.oix, f.ex);
+    rayf_axis(o.y, d.y, S, f.idy, f.oiy, f.ey);
+    rayf_axis(o.z, d.z, S, f.idz, f.oiz, f.ez);
+    return f;
+}
+PT_DEV bool slab_f32(const float* lo, const float* hi, const RayF& f, float t_min, float t_max, float& t_near) {
+    const float t1x = __builtin_fmaf(lo[0], f.idx, -f.oix), t2x = __builtin_fmaf(hi[0], f.idx, -f.oix);
+    const float t1y = __builtin_fmaf(lo[1], f.idy, -f.oiy), t2y = __builtin_fmaf(hi[1], f.idy, -f.oiy);
+    const float t1z = __builtin_fmaf(lo[2], f.idz, -f.oiz), t2z = __builtin_fmaf(hi[2], f.idz, -f.oiz);
+    const float nx = fminf(t1x, t2x) - f.ex, fx = fmaxf(t1x, t2x) + f.ex;
+    const float ny = fminf(t1y, t2y) - f.ey, fy = fmaxf(t1y, t2y) + f.ey;
+    const float nz = fminf(t1z, t2z) - f.ez, fz = fmaxf(t1z, t2z) + f.ez;
+    const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, t_min));
+    const float tf = fminf(fminf(fx, fy), fminf(fz, t_max));
+    t_near = tn;
+    return tn <= tf;
+}
+// f64 reference slab test (aabb.rs:31-42 arithmetic on the padded boxes); kept for A/B debugging
+PT_DEV bool slab_f64(const float* lo, const float* hi, V3 o, V3 inv, double t_min, double t_max, double& t_near) {
     double t1x = ((double)lo[0] - o.x) * inv.x, t2x = ((double)hi[0] - o.x) * inv.x;
     double t1y = ((double)lo[1] - o.y) * inv.y, t2y = ((double)hi[1] - o.y) * inv.y;
     double t1z = ((double)lo[2] - o.z) * inv.z, t2z = ((double)hi[2] - o.z) * inv.z;
@@ -43,27 +85,25 @@ PT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv, double t_min, d
     t_near = tn;
     return tn <= tf;
 }
-// 1/d for the fma slab test, clamped to a finite magnitude: with d == 0 (exactly axis-parallel
-// rays DO occur: a direction sampled inside the plane of an axis-aligned light) 1/d = inf would
-// turn lo*inv - o*inv into inf - inf = NaN and a NaN-ignoring min/max then drops the wrong end of
-// the slab interval. With |inv| <= 1e290 every product stays finite and the axis behaves like
-// "parallel": (-huge, +huge) when the origin is inside the slab, empty when it is outside.
-PT_DEV double safe_inv(double d) {
-    double i = 1.0 / d;
-    if (!(fabs(i) <= 1e290)) i = __builtin_copysign(1e290, d);
-    return i;
+// one BVH2 node: both children tested, near-first order; returns the number of children to visit
+PT_DEV int visit_node(const BvhNode* nd, const RayF& f, float t_min, float t_max, uint32_t& first, uint32_t& second) {
+    const float4 q0 = ((const float4*)nd)[0], q1 = ((const float4*)nd)[1], q2 = ((const float4*)nd)[2];
+    const uint4 q3 = ((const uint4*)nd)[3];
+    const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+    const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+    float tn0, tn1;
+    const bool h0 = slab_f32(lo0, hi0, f, t_min, t_max, tn0);
+    const bool h1 = slab_f32(lo1, hi1, f, t_min, t_max, tn1);
+    if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        first = swap ? q3.y : q3.x;
+        second = swap ? q3.x : q3.y;
+        return 2;
+    }
+    first = h0 ? q3.x : q3.y;
+    return (h0 || h1) ? 1 : 0;
 }
-PT_DEV V3 safe_inv3(V3 d) { return V3{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)}; }
-PT_DEV bool slab_fma(const float* lo, const float* hi, V3 inv, V3 oi, double t_min, double t_max, double& t_near) {
-    double t1x = __builtin_fma((double)lo[0], inv.x, -oi.x), t2x = __builtin_fma((double)hi[0], inv.x, -oi.x);
-    double t1y = __builtin_fma((double)lo[1], inv.y, -oi.y), t2y = __builtin_fma((double)hi[1], inv.y, -oi.y);
-    double t1z = __builtin_fma((double)lo[2], inv.z, -oi.z), t2z = __builtin_fma((double)hi[2], inv.z, -oi.z);
-    double tn = fmax(fmax(fmin(t1x, t2x), fmin(t1y, t2y)), fmax(fmin(t1z, t2z), t_min));
-    double tf = fmin(fmin(fmax(t1x, t2x), fmax(t1y, t2y)), fmin(fmax(t1z, t2z), t_max));
-    t_near = tn;
-    return tn <= tf;
-}
-
+PT_DEV float t_max_f32(double t) { return __double2float_ru(t); }   // rounded UP: conservative upper end
 
 PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint32_t gid, Closest& best) {
     const PrimRef pr = sc.prims[gid];
@@ -77,50 +117,51 @@ PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint3
     }
 }
 
-template <bool FMA>
+template <bool F32>
 PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uint32_t* stk /* &stack[0][lane] */) {
     Closest best{D_INF, HIT_NONE};
     RayD r = wray;
-    V3 inv{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
+    RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
+    V3 inv{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};   // f64 variant only
+    const float t_min_f = __double2float_rd(t_min);
+    float t_max_f = t_max_f32(best.t);
     int sp = 0;
     uint32_t cur = sc.tlas_root;
     for (;;) {
         if ((cur & REF_TYPE_MASK) == REF_NODE) {
             const BvhNode* nd = &sc.nodes[cur];
-            // 64-B node: four 16-B loads
-            const float4 q0 = ((const float4*)nd)[0], q1 = ((const float4*)nd)[1], q2 = ((const float4*)nd)[2];
-            const uint4 q3 = ((const uint4*)nd)[3];
-            const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
-            const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
-            double tn0, tn1;
-            const V3 sinv = safe_inv3(r.d), oi = r.o * sinv;
-            bool h0 = FMA ? slab_fma(lo0, hi0, sinv, oi, t_min, best.t, tn0) : slab(lo0, hi0, r.o, inv, t_min, best.t, tn0);
-            bool h1 = FMA ? slab_fma(lo1, hi1, sinv, oi, t_min, best.t, tn1) : slab(lo1, hi1, r.o, inv, t_min, best.t, tn1);
-            uint32_t c0 = q3.x, c1 = q3.y;
-            if (h0 && h1) {
-                if (tn1 < tn0) {
-                    uint32_t tmp = c0;
-                    c0 = c1;
-                    c1 = tmp;
-                }
-                if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = c1;
+            uint32_t c0, c1;
+            int n;
+            if (F32) {
+                n = visit_node(nd, f, t_min_f, t_max_f, c0, c1);
+            } else {
+                double tn0, tn1;
+                const bool h0 = slab_f64(nd->lo0, nd->hi0, r.o, inv, t_min, best.t, tn0);
+                const bool h1 = slab_f64(nd->lo1, nd->hi1, r.o, inv, t_min, best.t, tn1);
+                const bool swap = h0 && h1 && tn1 < tn0;
+                c0 = (h0 && !swap) ? nd->child0 : nd->child1;
+                c1 = swap ? nd->child0 : nd->child1;
+                n = (h0 ? 1 : 0) + (h1 ? 1 : 0);
+            }
+            if (n == 2 && sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = c1;
+            if (n > 0) {
                 cur = c0;
                 continue;
             }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
         } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
             for (uint32_t i = first; i < first + count; ++i) {
                 double t, u, v;
                 if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
             }
+            t_max_f = t_max_f32(best.t);
         } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
             const Entry e = sc.entries[cur & 0x3FFFFFFFu];
             RayD lr = wray;
             if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], wray);
             if (e.kind == ENTRY_MESH) {
                 r = lr;
+                f = make_rayf(r.o, r.d, e.extent);
                 inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
                 if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = REF_LEAVE_INSTANCE;
                 cur = e.blas_root;
@@ -128,8 +169,10 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
             }
             const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
             for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+            t_max_f = t_max_f32(best.t);
         } else if (cur == REF_LEAVE_INSTANCE) {
             r = wray;
+            f = make_rayf(r.o, r.d, sc.tlas_extent);
             inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
         }
         if (sp == 0) break;
@@ -138,15 +181,30 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
     return best;
 }
 
+// dynamic mode: work item -> (pixel, sample); false when the item lies outside a ragged image edge
+PT_DEV bool work_to_pixel(const PoolD& pool, unsigned long long w, uint32_t& pixel, uint32_t& sample) {
+    const uint32_t in_frame = (uint32_t)(w % pool.n_tile_pixels);
+    sample = pool.spp_begin + (uint32_t)(w / pool.n_tile_pixels);
+    const uint32_t tile = in_frame >> 6, in_tile = in_frame & 63u;
+    const uint32_t x = (tile % pool.tiles_x) * 8u + (in_tile & 7u), y = (tile / pool.tiles_x) * 8u + (in_tile >> 3);
+    pixel = y * pool.width + x;
+    return x < pool.width && y < pool.height;
+}
+// shard-local counter value -> global work item: 64-item chunks are dealt round-robin to the shards
+PT_DEV unsigned long long shard_item(unsigned long long c, uint32_t shard) {
+    return (c >> 6) * (unsigned long long)(WORK_SHARDS * 64u) + (unsigned long long)shard * 64ull + (c & 63ull);
+}
+
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t seed) {
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
         uint32_t pixel, sample;
         bool has_work;
-        if (pool.dynamic) {   // initial work items 0 .. n_slots-1 (the host starts next_work there)
-            pixel = s % pool.n_pixels;
-            sample = pool.spp_begin + s / pool.n_pixels;
+        bool idle = false;
+        if (pool.dynamic) {   // initial work items 0 .. n_slots-1 (the host starts the shard counters there)
             has_work = s < pool.n_slots && (unsigned long long)s < pool.total_work;
+            idle = has_work && !work_to_pixel(pool, s, pixel, sample);
+            if (!has_work || idle) { pixel = 0; sample = 0; }
             pool.pixel[s] = pixel;
         } else {
             pixel = s % pool.n_pixels;
@@ -159,8 +217,8 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
         pool.sample[s] = sample;
         pool.hit_prim[s] = HIT_NONE;
         pool.hit_t[s] = D_INF;
-        if (!has_work) {
-            pool.bounce[s] = SLOT_DEAD;
+        if (!has_work || idle) {
+            pool.bounce[s] = idle ? SLOT_IDLE : SLOT_DEAD;
             pool.draw[s] = 0;
             continue;
         }
@@ -181,7 +239,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     unsigned long long nseg = 0;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
-        if (pool.bounce[s] == SLOT_DEAD) continue;
+        if (pool.bounce[s] >= SLOT_IDLE) continue;
         RayD r{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
         Closest c = closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
         pool.hit_t[s] = c.t;
@@ -197,20 +255,25 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 // wave are idle, the idle lanes pull the next slots from a per-launch cursor (ballot + popcount +
 // one atomic per wave) and start traversing them while the others continue. Each loop iteration
 // performs ONE traversal step (node visit / triangle leaf / world entry / pop) per active lane.
-// Box tests use t = fma(b, 1/d, -o/d): they only have to be conservative (boxes are padded), the
-// primitive tests that decide the result keep the reference's exact arithmetic.
 __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, CountersD* cnt, int fetch_threshold) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     uint32_t* stk = &stack[threadIdx.x];
     const int lane = (int)(threadIdx.x & 63u);
     const double t_min = 1e-3;                                    // camera.rs:171,179
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->shade_cursor = 0;   // for the k_shade that follows
 
-    bool active = false, exhausted = false;
+    // this wave's contiguous share of the pool (multiples of 64 slots); refills walk it with a
+    // wave-uniform cursor — no atomics
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64), gw = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t per_wave = ((pool.n_alloc / 64 + n_waves - 1) / n_waves) * 64;
+    uint32_t cursor = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((unsigned long long)gw * per_wave, (unsigned long long)pool.n_alloc));
+    const uint32_t cursor_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((unsigned long long)cursor + per_wave, (unsigned long long)pool.n_alloc));
+    bool active = false, exhausted = cursor >= cursor_end;
     uint32_t slot = 0, cur = 0;
     int sp = 0;
     RayD r{};          // ray in the current space (world, or instance-local inside a mesh)
-    V3 inv{}, oi{};    // 1/d and o/d of r
+    RayF f{};          // its f32 reduction for the box tests
+    const float t_min_f = __double2float_rd(t_min);
+    float t_max_f = 0.0f;
     Closest best{D_INF, HIT_NONE};
     unsigned long long nseg = 0;
 
@@ -218,19 +281,17 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
         // ---- refill idle lanes ---------------------------------------------------------------
         const unsigned long long idle = __ballot(!active);
         if (!exhausted && (idle == ~0ull || __popcll(idle) >= fetch_threshold)) {
-            const int leader = __ffsll((long long)idle) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&cnt->extend_cursor, (unsigned long long)__popcll(idle));
-            base = __shfl(base, leader);
-            if (base >= pool.n_alloc) exhausted = true;           // wave-uniform
+            const uint32_t base = cursor;
+            cursor += (uint32_t)__popcll(idle);                   // wave-uniform
+            if (cursor >= cursor_end) exhausted = true;
             if (!active) {
-                const unsigned long long idx = base + (unsigned long long)__popcll(idle & ((1ull << lane) - 1ull));
-                if (idx < pool.n_alloc && pool.bounce[idx] != SLOT_DEAD) {
+                const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < cursor_end && pool.bounce[idx] < SLOT_IDLE) {
                     slot = (uint32_t)idx;
                     r = RayD{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, pool.time[slot]};
-                    inv = safe_inv3(r.d);
-                    oi = r.o * inv;
+                    f = make_rayf(r.o, r.d, sc.tlas_extent);
                     best = Closest{D_INF, HIT_NONE};
+                    t_max_f = t_max_f32(best.t);
                     sp = 0;
                     cur = sc.tlas_root;
                     active = true;
@@ -246,25 +307,11 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
         // ---- one traversal step ----------------------------------------------------------------
         bool pop = true;
         if ((cur & REF_TYPE_MASK) == REF_NODE) {
-            const BvhNode* nd = &sc.nodes[cur];
-            const float4 q0 = ((const float4*)nd)[0], q1 = ((const float4*)nd)[1], q2 = ((const float4*)nd)[2];
-            const uint4 q3 = ((const uint4*)nd)[3];
-            const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
-            const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
-            double tn0, tn1;
-            const bool h0 = slab_fma(lo0, hi0, inv, oi, t_min, best.t, tn0);
-            const bool h1 = slab_fma(lo1, hi1, inv, oi, t_min, best.t, tn1);
-            uint32_t c0 = q3.x, c1 = q3.y;
-            if (h0 && h1) {
-                if (tn1 < tn0) { const uint32_t tmp = c0; c0 = c1; c1 = tmp; }
-                if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = c1;
+            uint32_t c0, c1;
+            const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
+            if (n == 2 && sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = c1;
+            if (n > 0) {
                 cur = c0;
-                pop = false;
-            } else if (h0) {
-                cur = c0;
-                pop = false;
-            } else if (h1) {
-                cur = c1;
                 pop = false;
             }
         } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
@@ -273,25 +320,25 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
                 double t, u, v;
                 if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
             }
+            t_max_f = t_max_f32(best.t);
         } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
             const Entry e = sc.entries[cur & 0x3FFFFFFFu];
             RayD lr = r;                                          // world space here (entries live in the TLAS)
             if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
             if (e.kind == ENTRY_MESH) {
                 r = lr;
-                inv = safe_inv3(r.d);
-                oi = r.o * inv;
+                f = make_rayf(r.o, r.d, e.extent);
                 if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = REF_LEAVE_INSTANCE;
                 cur = e.blas_root;
                 pop = false;
             } else {
                 const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
                 for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+                t_max_f = t_max_f32(best.t);
             }
         } else if (cur == REF_LEAVE_INSTANCE) {                   // back to world space: reload the ray
             r = RayD{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, r.time};
-            inv = safe_inv3(r.d);
-            oi = r.o * inv;
+            f = make_rayf(r.o, r.d, sc.tlas_extent);
         }
         if (pop) {
             if (sp == 0) {
@@ -308,18 +355,18 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
 
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     unsigned long long n_done = 0, n_died = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->extend_cursor = 0;   // for the k_extend that follows
     // n_alloc is a multiple of 64 and the stride a multiple of 256, so whole waves enter or skip an
     // iteration together: the wave-level ballot below sees all 64 lanes.
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
         uint32_t bounce = pool.bounce[s];
         const bool alive = bounce != SLOT_DEAD;
-        bool finished = false;
+        const bool was_idle = bounce == SLOT_IDLE;
+        bool finished = was_idle;
         uint32_t pixel = 0;
         RayD ray{};
         V3 thr{}, rad{};
         Rng rng{};
-        if (alive) {
+        if (alive && !was_idle) {
             pixel = pool.dynamic ? pool.pixel[s] : s % pool.n_pixels;
             ray = RayD{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
             thr = V3{pool.tx[s], pool.ty[s], pool.tz[s]};
@@ -370,7 +417,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneD sc, CamD cam, PoolD pool
         }
         // ---- finished paths: accumulate (camera.rs:107) and regenerate in place -----------------
         uint32_t next_pixel = pixel, next_sample = 0;
-        bool more = false;
+        bool more = false, next_idle = false;
         if (pool.dynamic) {
             // K5: wave ballot + prefix popcount, ONE atomic per wave on the global work counter
             const unsigned long long mask = __ballot(alive && finished);
@@ -378,17 +425,19 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneD sc, CamD cam, PoolD pool
                 const int lane = (int)(threadIdx.x & 63u);
                 const int leader = __ffsll((long long)mask) - 1;
                 unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(&cnt->next_work, (unsigned long long)__popcll(mask));
+                const uint32_t shard = blockIdx.x % WORK_SHARDS;
+                if (lane == leader) base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(mask));
                 base = __shfl(base, leader);
                 if (alive && finished) {
-                    const unsigned long long w = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], rad.x);
-                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], rad.y);
-                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], rad.z);
+                    const unsigned long long w = shard_item(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)), shard);
+                    if (!was_idle) {
+                        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], rad.x);
+                        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], rad.y);
+                        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], rad.z);
+                    }
                     if (w < pool.total_work) {
                         more = true;
-                        next_pixel = (uint32_t)(w % pool.n_pixels);
-                        next_sample = pool.spp_begin + (uint32_t)(w / pool.n_pixels);
+                        next_idle = !work_to_pixel(pool, w, next_pixel, next_sample);
                     }
                 }
             }
@@ -398,8 +447,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneD sc, CamD cam, PoolD pool
             more = next_sample < pool.spp_end;
         }
         if (alive && finished) {
-            ++n_done;
-            if (more) {
+            if (!was_idle) ++n_done;
+            if (more && next_idle) {
+                bounce = SLOT_IDLE;
+            } else if (more) {
                 rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), next_pixel, next_sample, 0u};
                 ray = generate_ray(cam, next_pixel / cam.width, next_pixel % cam.width, rng);
                 thr = V3{1.0, 1.0, 1.0};
@@ -414,7 +465,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneD sc, CamD cam, PoolD pool
         }
         if (alive) {
             pool.bounce[s] = bounce;
-            if (bounce != SLOT_DEAD) {
+            if (bounce < SLOT_IDLE) {
                 pool.ox[s] = ray.o.x; pool.oy[s] = ray.o.y; pool.oz[s] = ray.o.z;
                 pool.dx[s] = ray.d.x; pool.dy[s] = ray.d.y; pool.dz[s] = ray.d.z;
                 pool.time[s] = ray.time;

@@ -200,7 +200,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     uint32_t k = opts.slots_per_pixel;
     if (const char* e = getenv("PT_SLOTS_PER_PIXEL")) k = (uint32_t)atoi(e);
     const bool dynamic = k == 0;
-    const uint64_t total_work = (uint64_t)n_pixels * spp;
+    const uint32_t tiles_x = (dc.width + 7) / 8, tiles_y = (dc.height + 7) / 8;
+    const uint64_t n_tile_pixels64 = (uint64_t)tiles_x * tiles_y * 64;
+    if (n_tile_pixels64 > 0x7FFFFFFFull) return set_error("pt_render: image too large");
+    const uint64_t total_work = dynamic ? n_tile_pixels64 * spp : (uint64_t)n_pixels * spp;
     uint64_t n_slots64;
     if (dynamic) {
         uint64_t target = (uint64_t)ctx->n_cus * 16384ull;   // ~4M resident paths on 256 CUs
@@ -247,6 +250,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     pool.spp_end = spp_end;
     pool.dynamic = dynamic ? 1u : 0u;
     pool.total_work = total_work;
+    pool.width = dc.width;
+    pool.height = dc.height;
+    pool.tiles_x = tiles_x;
+    pool.n_tile_pixels = (uint32_t)n_tile_pixels64;
 
     // accumulator on the device
     double* d_accum = accum;
@@ -270,7 +277,11 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     CountersD init_cnt;
     memset(&init_cnt, 0, sizeof init_cnt);
     init_cnt.alive = spp == 0 ? 0 : n_slots;   // every slot starts with one sample (k <= spp / n_slots <= total_work)
-    init_cnt.next_work = n_slots;              // dynamic mode: items 0 .. n_slots-1 are handed out by k_init
+    for (uint32_t sh = 0; sh < WORK_SHARDS; ++sh) {   // dynamic mode: items 0 .. n_slots-1 were handed out by k_init
+        const uint64_t row = (uint64_t)WORK_SHARDS * 64, rows = n_slots / row, rem = n_slots % row;
+        const uint64_t part = rem > (uint64_t)sh * 64 ? std::min<uint64_t>(rem - (uint64_t)sh * 64, 64) : 0;
+        init_cnt.work[sh].next = rows * 64 + part;
+    }
     if (!hip_ok(hipMemcpyAsync(s->d_counters, &init_cnt, sizeof init_cnt, hipMemcpyHostToDevice, st), "hipMemcpy(counters)")) return -1;
 
     EventTimer timer;

@@ -414,6 +414,14 @@ bool upload(DeviceBuffers& dev, const std::vector<T>& v, const T*& out) {
     out = (const T*)p;
     return true;
 }
+// max |coordinate| of a subtree's bounds, as the f32 slab test's error margin needs it: padded like
+// the stored boxes and rounded up
+float box_extent(const Box& b) {
+    double m = 1e-3;
+    const double v[6] = {b.lo.x, b.lo.y, b.lo.z, b.hi.x, b.hi.y, b.hi.z};
+    for (double x : v) m = std::fmax(m, std::fabs(x));
+    return std::nextafterf((float)(m * 1.000001), INFINITY);
+}
 Box sphere_box(const SphereD& s) {
     Box b;
     D3 r{s.r, s.r, s.r};
@@ -478,6 +486,7 @@ int pt::scene_build(pt_scene* s) {
             lights.push_back((uint32_t)entries.size());
         }
         Entry e{};
+        memset(&e, 0, sizeof e);
         e.first_prim = (uint32_t)prims.size();
         e.inst = inst;
         e.blas_root = REF_EMPTY;
@@ -515,6 +524,7 @@ int pt::scene_build(pt_scene* s) {
             Box bb;
             e.blas_root = bl.build(0, items.size(), 0, bb);
             max_blas_depth = std::max(max_blas_depth, bl.depth_reached);
+            e.extent = box_extent(bb);
             const uint32_t flags = PRIM_TRI | (o->has_normals ? PRIM_HAS_NORMALS : 0u) | (o->has_uvs ? PRIM_HAS_UVS : 0u);
             const uint32_t gid_base = (uint32_t)prims.size();
             prims.resize(prims.size() + o->tris.size());
@@ -562,6 +572,7 @@ int pt::scene_build(pt_scene* s) {
         return -1;
     }
     v.tlas_root = tlas_root;
+    v.tlas_extent = box_extent(wb);
     v.n_entries = (uint32_t)entries.size();
     v.n_prims = (uint32_t)prims.size();
     v.n_lights = (uint32_t)lights.size();

@@ -8,8 +8,9 @@ namespace pt {
 
 // ---- BVH -----------------------------------------------------------------------------
 // One node format for the top-level tree (over world objects) and every per-mesh tree.
-// Boxes are stored as f32 rounded OUTWARD from the padded f64 bounds (conservative), the
-// slab test itself runs in f64 against the f64 ray. 64 B = four 16-B loads per visit.
+// Boxes are stored as f32 rounded OUTWARD from the padded f64 bounds (conservative); the slab
+// test runs in f32 with a per-ray error margin (pt_kernels.hip, slab_f32) — box tests only have
+// to be conservative, the f64 primitive tests decide the result. 64 B = four 16-B loads per visit.
 // Child reference (32 bit):
 //   00xx.. internal node index
 //   01cc cfff.. triangle leaf: ccc = count-1 (1..8), f = first triangle (BLAS order)
@@ -47,6 +48,8 @@ struct Entry {           // one per world-level object (lights list first, then 
     uint32_t first_prim; // global id of its first primitive
     int32_t inst;
     uint32_t blas_root;  // node index (ENTRY_MESH)
+    float extent;        // ENTRY_MESH: max |coordinate| of the mesh's (local-space) BVH boxes
+    uint32_t pad[3];
 };
 struct SphereD { double r, p1[3], p2[3]; };
 struct QuadD { double q[3], u[3], v[3], w[3], n[3], d; };
@@ -99,6 +102,7 @@ struct SceneD {
     const uint8_t* atlas;
     const uint32_t* lights;      // entry indices of the lights list
     uint32_t tlas_root;          // child reference of the top-level root
+    float tlas_extent;           // max |coordinate| of the top-level BVH boxes
     uint32_t n_entries, n_prims, n_lights;
 };
 
@@ -110,10 +114,14 @@ struct SceneD {
 //  dynamic (default): a finished path pulls the next (pixel, sample) work item from one global
 //          counter — wave-aggregated: ballot + popcount + one atomic per wave — so every lane
 //          stays busy until the frame's sample budget is exhausted; radiance is added to the
-//          frame accumulator with hardware f64 atomics. Work item i -> pixel i % n_pixels,
-//          sample spp_begin + i / n_pixels (neighbouring lanes start on neighbouring pixels).
+//          frame accumulator with hardware f64 atomics. Work items are ordered sample-major and,
+//          inside a sample, by 8x8 PIXEL TILES (item % (tiles*64) -> tile, pixel in tile), so that
+//          the 64 lanes of a wave start on one compact tile: primary rays — half of all segments
+//          in scene 6 — stay coherent in traversal and in material. Items that fall outside a
+//          ragged image edge are skipped (slot state SLOT_IDLE for one iteration).
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 constexpr uint32_t SLOT_DEAD = 0xFFFFFFFFu;   // value of `bounce` for a finished slot
+constexpr uint32_t SLOT_IDLE = 0xFFFFFFFEu;   // dynamic mode: drew an item outside the image, draws again next iteration
 struct PoolD {
     double *ox, *oy, *oz, *dx, *dy, *dz, *time;   // current ray (direction normalised)
     double *tx, *ty, *tz;                         // throughput
@@ -128,15 +136,20 @@ struct PoolD {
     uint32_t n_slots, n_pixels, k;                // k = slots per pixel (static mode)
     uint32_t spp_begin, spp_end;
     uint32_t dynamic, n_alloc;                    // n_alloc: slots rounded up to a multiple of 64
+    uint32_t width, height, tiles_x, n_tile_pixels;   // dynamic mode: 8x8 tiling, n_tile_pixels = tiles_x*tiles_y*64
 };
 
+// The work counter of the dynamic mode is SHARDED: one word saturates at ~88 dequeues/us on this
+// chip (MI355X_MICROARCH.md, row "dequeue") and a frame needs one dequeue per wave per iteration
+// (65k per launch at 4M resident paths), which alone would cost ~0.75 ms per launch. Shard s hands
+// out the work items w with w % WORK_SHARDS == s; a block always uses shard blockIdx.x % WORK_SHARDS.
+constexpr uint32_t WORK_SHARDS = 64;
 struct CountersD {
     unsigned long long alive;        // slots still rendering
     unsigned long long segments;     // extend() calls on live paths
     unsigned long long samples;      // finished samples
-    unsigned long long next_work;    // dynamic mode: next unassigned work item
-    unsigned long long extend_cursor;   // per-launch slot cursor of k_extend's dynamic ray fetch (reset by k_shade)
-    unsigned long long shade_cursor;    // per-launch cursor of k_shade (reset by k_extend)
+    unsigned long long pad[13];
+    struct alignas(128) Shard { unsigned long long next; unsigned long long pad[15]; } work[WORK_SHARDS];
 };
 
 }  // namespace pt
