@@ -7,11 +7,11 @@
 namespace pt {
 void launch_init(const CamD& cam, const PoolD& pool, uint64_t seed, int max_blocks, hipStream_t st);
 void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int fetch_threshold, hipStream_t st);
-void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks,
+void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
                   hipStream_t st);
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st);
 void launch_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8, hipStream_t st);
 void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, int variant, hipStream_t st);
 void launch_math_probe(int which, const double* in, uint32_t n, double* out, hipStream_t st);
-int kernel_occupancy_blocks(int which);   // 0 = extend, 1 = shade; resident blocks per CU
+int kernel_occupancy_blocks(int which, int variant);   // 0 = extend, 1 = shade; resident blocks per CU
 }  // namespace pt

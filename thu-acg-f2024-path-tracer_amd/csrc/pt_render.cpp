@@ -218,7 +218,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     if (n_slots64 > 0x7FFFFFC0ull) return set_error("pt_render: image too large for the path pool");
     const uint32_t n_slots = (uint32_t)n_slots64;
     // one allocation, carved into the SoA arrays (17 f64 + 5 u32 per slot)
-    const size_t n_al = ((size_t)n_slots + 63) & ~(size_t)63;
+    const size_t n_al = ((size_t)n_slots + 255) & ~(size_t)255;   // whole 256-slot chunks (k_shade sorts per chunk)
     const size_t bytes = n_al * (17 * sizeof(double) + 5 * sizeof(uint32_t));
     if (bytes > s->pool_bytes) {
         if (s->pool_mem) (void)hipFree(s->pool_mem);
@@ -266,14 +266,16 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     // persistent grids: resident blocks per CU x CUs
     int mult = 1;
     if (const char* e = getenv("PT_GRID_MULT")) mult = std::max(1, atoi(e));
-    const int blocks_extend = kernel_occupancy_blocks(0), blocks_shade = kernel_occupancy_blocks(1);
+    int shade_variant = 2;   // k_shade<sort, min waves/SIMD>: sort*10 + waves
+    if (const char* e = getenv("PT_SHADE_VARIANT")) shade_variant = atoi(e);
+    int fetch_threshold = 0;
+    if (const char* e = getenv("PT_FETCH_THRESHOLD")) fetch_threshold = std::min(64, std::max(0, atoi(e)));
+    const int blocks_extend = kernel_occupancy_blocks(0, fetch_threshold), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;
-    // K2 variant: 0 = batch kernel (default); n in 1..64 = persistent dynamic-fetch kernel that
-    // refills a wave when >= n of its 64 lanes are idle (experimental)
-    int fetch_threshold = 0;
-    if (const char* e = getenv("PT_FETCH_THRESHOLD")) fetch_threshold = std::min(64, std::max(0, atoi(e)));
+    // K2 variant (fetch_threshold): 0 = batch kernel (default); n in 1..64 = persistent dynamic-fetch
+    // kernel that refills a wave when >= n of its 64 lanes are idle (experimental)
     CountersD init_cnt;
     memset(&init_cnt, 0, sizeof init_cnt);
     init_cnt.alive = spp == 0 ? 0 : n_slots;   // every slot starts with one sample (k <= spp / n_slots <= total_work)
@@ -308,7 +310,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
             launch_extend(s->dev.view, pool, s->d_counters, grid_extend, fetch_threshold, st);
             timer.end(st);
             timer.begin(1, st);
-            launch_shade(s->dev.view, dc, pool, s->d_counters, seed, grid_shade, st);
+            launch_shade(s->dev.view, dc, pool, s->d_counters, seed, grid_shade, shade_variant, st);
             timer.end(st);
             ++iterations;
         }
