@@ -353,166 +353,216 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
     if (nseg) atomicAdd(&cnt->segments, nseg);
 }
 
-// K3. Each block walks the pool in chunks of 256 slots and first SORTS the chunk by material class
-// in LDS (wave ballots -> per-wave histograms -> counting sort of the 256 lane ids): misses,
-// diffuse, metal, glass, principled, light, idle and dead slots end up in contiguous lane ranges,
-// so most waves shade ONE kind of material instead of serialising through all of them (the first
-// profile showed 21 % VALU lane utilisation without it). State accesses stay inside the chunk's
-// 2 KB-per-array window, i.e. they remain coalescable.
+// K3: the body of camera.rs:177-226 for the path in slot `s`, executed by all 64 lanes of a wave
+// together (it contains wave-level ballots for the work-counter dequeue, K5).
+PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane,
+                       unsigned long long& n_done, unsigned long long& n_died) {
+    uint32_t bounce = pool.bounce[s];
+    const bool alive = bounce != SLOT_DEAD;
+    const bool was_idle = bounce == SLOT_IDLE;
+    bool finished = was_idle;
+    uint32_t pixel = 0;
+    RayD ray{};
+    V3 thr{}, rad{};
+    Rng rng{};
+    if (alive && !was_idle) {
+        pixel = pool.dynamic ? pool.pixel[s] : s % pool.n_pixels;
+        ray = RayD{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
+        thr = V3{pool.tx[s], pool.ty[s], pool.tz[s]};
+        rad = V3{pool.rx[s], pool.ry[s], pool.rz[s]};
+        rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, pool.sample[s], pool.draw[s]};
+        const uint32_t gid = pool.hit_prim[s];
+        HitD hit;
+        if (gid == HIT_NONE || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
+            rad = rad + thr * sample_environment(sc, cam, ray.d);   // camera.rs:180-183
+            finished = true;
+        } else {
+            const MatD& m = sc.mats[hit.mat];
+            // camera.rs:186-187 — added for every material (zero unless emissive) so that a
+            // non-finite throughput poisons the sample exactly as it does in the reference
+            V3 emission = m.kind == MAT_LIGHT ? tex_rgb(sc, m.color_tex, hit.u, hit.v, hit.point) : V3{0.0, 0.0, 0.0};
+            rad = rad + thr * emission;
+            if (bounce > 5) {                                        // russian roulette :190-196
+                double p = clampd(luminance(thr), 0.01, 1.0);
+                if (rng_f64(rng) > p) finished = true;
+                else thr = thr / p;
+            }
+            if (!finished) {
+                const double p_light = sc.n_lights == 0 ? 0.0 : 0.5;   // :199-200
+                const double p_bsdf = 1.0 - p_light;
+                const V3 wo = -ray.d;
+                double rsel = rng_f64(rng);
+                V3 dir;
+                bool ok = true;
+                if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
+                else ok = mat_sample(sc, m, hit, wo, rng, cam.two_pi_scale, dir);
+                if (!ok) {
+                    finished = true;                                 // :209-211
+                } else {
+                    double bsdf_pdf;
+                    V3 brdf;
+                    mat_pdf_eval(sc, m, hit, wo, dir, bsdf_pdf, brdf);
+                    double light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
+                    double pdf = p_bsdf * bsdf_pdf + p_light * light_pdf;
+                    V3 attenuation = brdf / pdf;
+                    double e = 1e-3 * signum(dot(dir, hit.gn));      // :217-222
+                    ray = make_ray(hit.point + e * hit.gn, dir, ray.time);
+                    thr = thr * attenuation;
+                    ++bounce;
+                    if (bounce >= cam.max_depth) finished = true;    // loop bound :177
+                }
+            }
+        }
+    }
+    // ---- finished paths: accumulate (camera.rs:107) and regenerate in place -----------------
+    uint32_t next_pixel = pixel, next_sample = 0;
+    bool more = false, next_idle = false;
+    if (pool.dynamic) {
+        // K5: wave ballot + prefix popcount, ONE atomic per wave on the global work counter
+        const unsigned long long mask = __ballot(alive && finished);
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            unsigned long long base = 0;
+            const uint32_t shard = blockIdx.x % WORK_SHARDS;
+            if (lane == leader) base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(mask));
+            base = __shfl(base, leader);
+            if (alive && finished) {
+                const unsigned long long w = shard_item(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)), shard);
+                if (!was_idle) {
+                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], rad.x);
+                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], rad.y);
+                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], rad.z);
+                }
+                if (w < pool.total_work) {
+                    more = true;
+                    next_idle = !work_to_pixel(pool, w, next_pixel, next_sample);
+                }
+            }
+        }
+    } else if (alive && finished) {
+        pool.ax[s] += rad.x; pool.ay[s] += rad.y; pool.az[s] += rad.z;
+        next_sample = pool.sample[s] + pool.k;
+        more = next_sample < pool.spp_end;
+    }
+    if (alive && finished) {
+        if (!was_idle) ++n_done;
+        if (more && next_idle) {
+            bounce = SLOT_IDLE;
+        } else if (more) {
+            rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), next_pixel, next_sample, 0u};
+            ray = generate_ray(cam, next_pixel / cam.width, next_pixel % cam.width, rng);
+            thr = V3{1.0, 1.0, 1.0};
+            rad = V3{0.0, 0.0, 0.0};
+            bounce = 0;
+            pool.sample[s] = next_sample;
+            if (pool.dynamic) pool.pixel[s] = next_pixel;
+        } else {
+            bounce = SLOT_DEAD;
+            ++n_died;
+        }
+    }
+    if (alive) {
+        pool.bounce[s] = bounce;
+        if (bounce < SLOT_IDLE) {
+            pool.ox[s] = ray.o.x; pool.oy[s] = ray.o.y; pool.oz[s] = ray.o.z;
+            pool.dx[s] = ray.d.x; pool.dy[s] = ray.d.y; pool.dz[s] = ray.d.z;
+            pool.time[s] = ray.time;
+            pool.tx[s] = thr.x; pool.ty[s] = thr.y; pool.tz[s] = thr.z;
+            pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z;
+            pool.draw[s] = rng.draw;
+        }
+    }
+}
+
+constexpr int SORT_WINDOW = 2048;   // slots sorted together by k_shade<true, *>
+
+// K3 launcher kernel. SORT = false: blocks walk the pool in 256-slot chunks, lane i shades slot i.
+// SORT = true: a block takes a WINDOW of 2048 slots, counting-sorts their indices by material class
+// in LDS (miss, diffuse, metal, glass, principled, light, idle, dead), then its four waves pull
+// groups of 64 same-class slots from an LDS cursor until the window is done — waves execute one
+// material's code instead of serialising through all of them, the expensive classes are spread over
+// all waves of the block (work stealing), and state accesses stay inside the window's 16 KB-per-array
+// range.
 template <bool SORT, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
-    __shared__ uint32_t s_cnt[BLOCK / 64][8];
-    __shared__ uint16_t s_perm[BLOCK];
     unsigned long long n_done = 0, n_died = 0;
-    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    // n_alloc is a multiple of 256: all threads of a block run every chunk (barriers + wave ballots)
-    for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK) {
-        if (SORT) {
-            const uint32_t s0 = base + threadIdx.x;
-            const uint32_t b0 = pool.bounce[s0];
-            uint32_t key;
-            if (b0 == SLOT_DEAD) key = 7u;
-            else if (b0 == SLOT_IDLE) key = 6u;
-            else {
-                const uint32_t g0 = pool.hit_prim[s0];
-                key = g0 == HIT_NONE ? 0u : 1u + sc.mats[sc.prims[g0].mat].kind;
-            }
-            uint32_t myrank = 0;
+    const int lane = (int)(threadIdx.x & 63u);
+    if (!SORT) {
+        // n_alloc is a multiple of 256: whole waves run every chunk (wave ballots inside shade_slot)
+        for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK)
+            shade_slot(sc, cam, pool, cnt, seed, base + threadIdx.x, lane, n_done, n_died);
+    } else {
+        __shared__ uint16_t s_perm[SORT_WINDOW];
+        __shared__ uint32_t s_cnt[8][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
+        __shared__ uint32_t s_hist[8], s_next;
+        constexpr int PER = SORT_WINDOW / BLOCK, NGRP = SORT_WINDOW / 64;
+        const int wave = (int)(threadIdx.x >> 6);
+        for (uint32_t wbase = blockIdx.x * SORT_WINDOW; wbase < pool.n_alloc; wbase += gridDim.x * SORT_WINDOW) {
+            if (threadIdx.x == 0) s_next = 0;
+            // classify; STABLE counting sort (slot order is kept inside a class, so the work items a
+            // wave dequeues — consecutive pixels of one tile — land in neighbouring slots and the next
+            // k_extend sees coherent primary rays)
+            uint32_t keys = 0, ranks = 0;   // 8 x 4-bit class keys, 8 x ... ranks kept separately below
+            uint32_t rank[PER];
 #pragma unroll
-            for (uint32_t k = 0; k < 8u; ++k) {
-                const unsigned long long m = __ballot(key == k);
-                if (key == k) myrank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (lane == 0) s_cnt[wave][k] = (uint32_t)__popcll(m);
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t s0 = wbase + (uint32_t)j * BLOCK + threadIdx.x;
+                const uint32_t b0 = pool.bounce[s0];
+                uint32_t key;
+                if (b0 == SLOT_DEAD) key = 7u;
+                else if (b0 == SLOT_IDLE) key = 6u;
+                else {
+                    const uint32_t g0 = pool.hit_prim[s0];
+                    key = g0 == HIT_NONE ? 0u : 1u + sc.mats[sc.prims[g0].mat].kind;
+                }
+                keys |= key << (4 * j);
+                rank[j] = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    const unsigned long long m = __ballot(key == k);
+                    if (key == k) rank[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (lane == 0) s_cnt[k][j * (BLOCK / 64) + wave] = (uint32_t)__popcll(m);
+                }
+            }
+            (void)ranks;
+            __syncthreads();
+            if (threadIdx.x < 8) {   // one thread per class: exclusive prefix over the groups in slot order
+                uint32_t acc = 0;
+                for (int g = 0; g < NGRP; ++g) {
+                    const uint32_t c = s_cnt[threadIdx.x][g];
+                    s_cnt[threadIdx.x][g] = acc;
+                    acc += c;
+                }
+                s_hist[threadIdx.x] = acc;
             }
             __syncthreads();
-            uint32_t off = 0;
+            uint32_t class_base[8];
+            {
+                uint32_t acc = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 8u; ++k)
+                for (int k = 0; k < 8; ++k) { class_base[k] = acc; acc += s_hist[k]; }
+            }
 #pragma unroll
-                for (int w = 0; w < BLOCK / 64; ++w) {
-                    const uint32_t c = s_cnt[w][k];
-                    if (k < key || (k == key && w < wave)) off += c;
-                }
-            s_perm[off + myrank] = (uint16_t)threadIdx.x;
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t key = (keys >> (4 * j)) & 15u;
+                uint32_t cb = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cb = key == (uint32_t)k ? class_base[k] : cb;
+                const uint32_t pos = cb + s_cnt[key][j * (BLOCK / 64) + wave] + rank[j];
+                s_perm[pos] = (uint16_t)(j * BLOCK + threadIdx.x);
+            }
             __syncthreads();
-        }
-        const uint32_t s = SORT ? base + s_perm[threadIdx.x] : base + threadIdx.x;
-        uint32_t bounce = pool.bounce[s];
-        const bool alive = bounce != SLOT_DEAD;
-        const bool was_idle = bounce == SLOT_IDLE;
-        bool finished = was_idle;
-        uint32_t pixel = 0;
-        RayD ray{};
-        V3 thr{}, rad{};
-        Rng rng{};
-        if (alive && !was_idle) {
-            pixel = pool.dynamic ? pool.pixel[s] : s % pool.n_pixels;
-            ray = RayD{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
-            thr = V3{pool.tx[s], pool.ty[s], pool.tz[s]};
-            rad = V3{pool.rx[s], pool.ry[s], pool.rz[s]};
-            rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, pool.sample[s], pool.draw[s]};
-            const uint32_t gid = pool.hit_prim[s];
-            HitD hit;
-            if (gid == HIT_NONE || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
-                rad = rad + thr * sample_environment(sc, cam, ray.d);   // camera.rs:180-183
-                finished = true;
-            } else {
-                const MatD& m = sc.mats[hit.mat];
-                // camera.rs:186-187 — added for every material (zero unless emissive) so that a
-                // non-finite throughput poisons the sample exactly as it does in the reference
-                V3 emission = m.kind == MAT_LIGHT ? tex_rgb(sc, m.color_tex, hit.u, hit.v, hit.point) : V3{0.0, 0.0, 0.0};
-                rad = rad + thr * emission;
-                if (bounce > 5) {                                        // russian roulette :190-196
-                    double p = clampd(luminance(thr), 0.01, 1.0);
-                    if (rng_f64(rng) > p) finished = true;
-                    else thr = thr / p;
-                }
-                if (!finished) {
-                    const double p_light = sc.n_lights == 0 ? 0.0 : 0.5;   // :199-200
-                    const double p_bsdf = 1.0 - p_light;
-                    const V3 wo = -ray.d;
-                    double rsel = rng_f64(rng);
-                    V3 dir;
-                    bool ok = true;
-                    if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
-                    else ok = mat_sample(sc, m, hit, wo, rng, cam.two_pi_scale, dir);
-                    if (!ok) {
-                        finished = true;                                 // :209-211
-                    } else {
-                        double bsdf_pdf;
-                        V3 brdf;
-                        mat_pdf_eval(sc, m, hit, wo, dir, bsdf_pdf, brdf);
-                        double light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
-                        double pdf = p_bsdf * bsdf_pdf + p_light * light_pdf;
-                        V3 attenuation = brdf / pdf;
-                        double e = 1e-3 * signum(dot(dir, hit.gn));      // :217-222
-                        ray = make_ray(hit.point + e * hit.gn, dir, ray.time);
-                        thr = thr * attenuation;
-                        ++bounce;
-                        if (bounce >= cam.max_depth) finished = true;    // loop bound :177
-                    }
-                }
+            const uint32_t n_live = SORT_WINDOW - s_hist[7];
+            for (;;) {
+                uint32_t g = 0;
+                if (lane == 0) g = atomicAdd(&s_next, 1u);
+                g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+                if (g * 64u >= n_live) break;
+                // lanes past n_live in the last group land on dead slots (sorted last): a no-op
+                shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[g * 64u + lane], lane, n_done, n_died);
             }
+            __syncthreads();   // LDS is reused by the next window
         }
-        // ---- finished paths: accumulate (camera.rs:107) and regenerate in place -----------------
-        uint32_t next_pixel = pixel, next_sample = 0;
-        bool more = false, next_idle = false;
-        if (pool.dynamic) {
-            // K5: wave ballot + prefix popcount, ONE atomic per wave on the global work counter
-            const unsigned long long mask = __ballot(alive && finished);
-            if (mask) {
-                const int leader = __ffsll((long long)mask) - 1;
-                unsigned long long base = 0;
-                const uint32_t shard = blockIdx.x % WORK_SHARDS;
-                if (lane == leader) base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(mask));
-                base = __shfl(base, leader);
-                if (alive && finished) {
-                    const unsigned long long w = shard_item(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)), shard);
-                    if (!was_idle) {
-                        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], rad.x);
-                        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], rad.y);
-                        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], rad.z);
-                    }
-                    if (w < pool.total_work) {
-                        more = true;
-                        next_idle = !work_to_pixel(pool, w, next_pixel, next_sample);
-                    }
-                }
-            }
-        } else if (alive && finished) {
-            pool.ax[s] += rad.x; pool.ay[s] += rad.y; pool.az[s] += rad.z;
-            next_sample = pool.sample[s] + pool.k;
-            more = next_sample < pool.spp_end;
-        }
-        if (alive && finished) {
-            if (!was_idle) ++n_done;
-            if (more && next_idle) {
-                bounce = SLOT_IDLE;
-            } else if (more) {
-                rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), next_pixel, next_sample, 0u};
-                ray = generate_ray(cam, next_pixel / cam.width, next_pixel % cam.width, rng);
-                thr = V3{1.0, 1.0, 1.0};
-                rad = V3{0.0, 0.0, 0.0};
-                bounce = 0;
-                pool.sample[s] = next_sample;
-                if (pool.dynamic) pool.pixel[s] = next_pixel;
-            } else {
-                bounce = SLOT_DEAD;
-                ++n_died;
-            }
-        }
-        if (alive) {
-            pool.bounce[s] = bounce;
-            if (bounce < SLOT_IDLE) {
-                pool.ox[s] = ray.o.x; pool.oy[s] = ray.o.y; pool.oz[s] = ray.o.z;
-                pool.dx[s] = ray.d.x; pool.dy[s] = ray.d.y; pool.dz[s] = ray.d.z;
-                pool.time[s] = ray.time;
-                pool.tx[s] = thr.x; pool.ty[s] = thr.y; pool.tz[s] = thr.z;
-                pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z;
-                pool.draw[s] = rng.draw;
-            }
-        }
-        if (SORT) __syncthreads();   // s_cnt / s_perm are reused by the next chunk
     }
     if (n_done) atomicAdd(&cnt->samples, n_done);
     if (n_died) atomicSub(&cnt->alive, n_died);
@@ -610,16 +660,15 @@ static shade_fn pick_shade(int variant) {   // variant = sort*10 + min waves per
     switch (variant) {
     case 2: return k_shade<false, 2>;
     case 3: return k_shade<false, 3>;
-    case 4: return k_shade<false, 4>;
     case 12: return k_shade<true, 2>;
     case 13: return k_shade<true, 3>;
-    case 14: return k_shade<true, 4>;
     default: return k_shade<false, 2>;
     }
 }
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
                   hipStream_t st) {
-    hipLaunchKernelGGL(pick_shade(variant), grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, cam, pool, cnt, seed);
+    const uint32_t units = variant >= 10 ? (pool.n_alloc / SORT_WINDOW) * BLOCK : pool.n_alloc;   // one block per window / chunk
+    hipLaunchKernelGGL(pick_shade(variant), grid_for(units, max_blocks), dim3(BLOCK), 0, st, sc, cam, pool, cnt, seed);
 }
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);

@@ -218,7 +218,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     if (n_slots64 > 0x7FFFFFC0ull) return set_error("pt_render: image too large for the path pool");
     const uint32_t n_slots = (uint32_t)n_slots64;
     // one allocation, carved into the SoA arrays (17 f64 + 5 u32 per slot)
-    const size_t n_al = ((size_t)n_slots + 255) & ~(size_t)255;   // whole 256-slot chunks (k_shade sorts per chunk)
+    const size_t n_al = ((size_t)n_slots + 2047) & ~(size_t)2047;   // whole 2048-slot windows (k_shade sorts per window)
     const size_t bytes = n_al * (17 * sizeof(double) + 5 * sizeof(uint32_t));
     if (bytes > s->pool_bytes) {
         if (s->pool_mem) (void)hipFree(s->pool_mem);
@@ -266,7 +266,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     // persistent grids: resident blocks per CU x CUs
     int mult = 1;
     if (const char* e = getenv("PT_GRID_MULT")) mult = std::max(1, atoi(e));
-    int shade_variant = 2;   // k_shade<sort, min waves/SIMD>: sort*10 + waves
+    int shade_variant = 12;   // k_shade<sort, min waves/SIMD>: sort*10 + waves (12 = windowed material sort, 2 = plain)
     if (const char* e = getenv("PT_SHADE_VARIANT")) shade_variant = atoi(e);
     int fetch_threshold = 0;
     if (const char* e = getenv("PT_FETCH_THRESHOLD")) fetch_threshold = std::min(64, std::max(0, atoi(e)));
