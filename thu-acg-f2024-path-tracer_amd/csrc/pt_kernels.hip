@@ -249,6 +249,158 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
     if (nseg) atomicAdd(&cnt->segments, nseg);
 }
 
+// ---------------------------------------------------------------------------------------
+// K2, two-phase form (default). The batch kernel above leaves most lanes idle: a sky ray is done
+// after ~5 steps while a lane next to it walks a mesh for 50-150 (17 % VALU lane utilisation in the
+// first profile). Here a block takes a WINDOW of 1024 slots and
+//   phase A: every ray walks only the TOP-LEVEL tree; spheres / quads / cuboids are intersected on
+//            the spot, mesh instances whose box it enters are only RECORDED (<= 4 per ray, in LDS);
+//   phase B: the rays that recorded something are compacted into an LDS list and the block's waves
+//            pull them 64 at a time (work stealing): each lane walks the recorded meshes of its ray
+//            one after the other, starting from the phase-A best hit.
+// Rays that never touch a mesh finish in the short, uniform phase A; the long mesh traversals run in
+// dense waves whose lanes all do the same kind of work. The closest hit is order-independent
+// (minimum t, ties -> larger id), so the result is bit-identical to the batch kernel's.
+// ---------------------------------------------------------------------------------------
+// EXT_STACK covers top-level depth + 1 + mesh depth (<= 10 + 1 + 20, enforced by the host builder)
+constexpr int EXT_WINDOW = 1024, EXT_STACK = 32, EXT_MAXI = 4;
+
+PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
+    RayD r = wray;
+    if (e.inst >= 0) r = ray_to_local(sc.insts[e.inst], wray);
+    const RayF f = make_rayf(r.o, r.d, e.extent);
+    float t_max_f = t_max_f32(best.t);
+    int sp = 0;
+    uint32_t cur = e.blas_root;
+    for (;;) {
+        if ((cur & REF_TYPE_MASK) == REF_NODE) {
+            uint32_t c0, c1;
+            const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
+            if (n == 2 && sp < cap) stk[(sp++) * BLOCK] = c1;
+            if (n > 0) {
+                cur = c0;
+                continue;
+            }
+        } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
+            const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
+            for (uint32_t i = first; i < first + count; ++i) {
+                double t, u, v;
+                if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
+            }
+            t_max_f = t_max_f32(best.t);
+        }
+        if (sp == 0) break;
+        cur = stk[(--sp) * BLOCK];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
+    __shared__ uint32_t stack[EXT_STACK * BLOCK];                 // 32 KB
+    __shared__ unsigned long long s_best_t[EXT_WINDOW];            //  8 KB  (bit pattern of the f64 t)
+    __shared__ uint32_t s_best_id[EXT_WINDOW];                     //  4 KB
+    __shared__ uint16_t s_items[EXT_WINDOW * EXT_MAXI];            //  8 KB  recorded mesh entries per ray
+    __shared__ uint8_t s_nitems[EXT_WINDOW];
+    __shared__ uint16_t s_rays[EXT_WINDOW];                        // rays with recorded meshes
+    __shared__ uint32_t s_nrays, s_next;
+    uint32_t* stk = &stack[threadIdx.x];
+    const int lane = (int)(threadIdx.x & 63u);
+    const double t_min = 1e-3;                                     // camera.rs:171,179
+    const float t_min_f = __double2float_rd(t_min);
+    unsigned long long nseg = 0;
+    for (uint32_t wbase = blockIdx.x * EXT_WINDOW; wbase < pool.n_alloc; wbase += gridDim.x * EXT_WINDOW) {
+        if (threadIdx.x == 0) { s_nrays = 0; s_next = 0; }
+        __syncthreads();
+        // ---- phase A: top-level tree only --------------------------------------------------------
+        for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) {
+            const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x, slot = wbase + sl;
+            const bool alive = pool.bounce[slot] < SLOT_IDLE;
+            uint32_t n_my = 0;
+            if (alive) {
+                ++nseg;
+                const RayD r{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, pool.time[slot]};
+                const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
+                Closest best{D_INF, HIT_NONE};
+                float t_max_f = t_max_f32(best.t);
+                int sp = 0;
+                uint32_t cur = sc.tlas_root;
+                for (;;) {
+                    if ((cur & REF_TYPE_MASK) == REF_NODE) {
+                        uint32_t c0, c1;
+                        const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
+                        if (n == 2 && sp < EXT_STACK) stk[(sp++) * BLOCK] = c1;
+                        if (n > 0) {
+                            cur = c0;
+                            continue;
+                        }
+                    } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
+                        const uint32_t ei = cur & 0x3FFFFFFFu;
+                        const Entry e = sc.entries[ei];
+                        if (e.kind == ENTRY_MESH) {
+                            if (n_my < (uint32_t)EXT_MAXI && ei < 0xFFFFu) {
+                                s_items[sl * EXT_MAXI + n_my++] = (uint16_t)ei;           // defer to phase B
+                            } else {
+                                blas_pass(sc, r, e, t_min, t_min_f, stk + (size_t)sp * BLOCK, EXT_STACK - sp, best);   // overflow: walk it now
+                                t_max_f = t_max_f32(best.t);
+                            }
+                        } else {
+                            RayD lr = r;
+                            if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
+                            const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;       // cuboid.rs: six quads, linear
+                            for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+                            t_max_f = t_max_f32(best.t);
+                        }
+                    } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
+                        // cannot happen at the top level (meshes are entries); kept for completeness
+                    }
+                    if (sp == 0) break;
+                    cur = stk[(--sp) * BLOCK];
+                }
+                if (n_my == 0) {
+                    pool.hit_t[slot] = best.t;
+                    pool.hit_prim[slot] = best.id;
+                } else {
+                    s_best_t[sl] = (unsigned long long)__double_as_longlong(best.t);
+                    s_best_id[sl] = best.id;
+                    s_nitems[sl] = (uint8_t)n_my;
+                }
+            }
+            // compact the rays that recorded meshes (slot order inside a wave is kept)
+            const unsigned long long m = __ballot(n_my > 0);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&s_nrays, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (n_my > 0) s_rays[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)sl;
+            }
+        }
+        __syncthreads();
+        // ---- phase B: mesh traversals, 64 rays per pull ------------------------------------------------
+        const uint32_t n_rays = s_nrays;
+        for (;;) {
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(&s_next, 1u);
+            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            if (g * 64u >= n_rays) break;
+            const uint32_t idx = g * 64u + (uint32_t)lane;
+            if (idx < n_rays) {
+                const uint32_t sl = s_rays[idx], slot = wbase + sl;
+                const RayD r{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, pool.time[slot]};
+                Closest best{__longlong_as_double((long long)s_best_t[sl]), s_best_id[sl]};
+                const uint32_t n_my = s_nitems[sl];
+                for (uint32_t k = 0; k < n_my; ++k) {
+                    const Entry e = sc.entries[s_items[sl * EXT_MAXI + k]];
+                    blas_pass(sc, r, e, t_min, t_min_f, stk, EXT_STACK, best);
+                }
+                pool.hit_t[slot] = best.t;
+                pool.hit_prim[slot] = best.id;
+            }
+        }
+        __syncthreads();   // LDS lists are reused by the next window
+    }
+    if (nseg) atomicAdd(&cnt->segments, nseg);
+}
+
 // K2 as a persistent-thread kernel with DYNAMIC RAY FETCH (Aila-Laine style): traversal lengths
 // vary by two orders of magnitude between a sky ray and a ray grazing a mesh, so a lane that
 // finishes its ray does not wait for the slowest lane of its wave — whenever enough lanes of the
@@ -652,7 +804,8 @@ void launch_init(const CamD& cam, const PoolD& pool, uint64_t seed, int max_bloc
     hipLaunchKernelGGL(k_init, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, cam, pool, seed);
 }
 void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int fetch_threshold, hipStream_t st) {
-    if (fetch_threshold <= 0) hipLaunchKernelGGL(k_extend, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    if (fetch_threshold == 0) hipLaunchKernelGGL(k_extend2, grid_for((pool.n_alloc / EXT_WINDOW) * BLOCK, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    else if (fetch_threshold < 0) hipLaunchKernelGGL(k_extend, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
     else hipLaunchKernelGGL(k_extend_fetch, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt, fetch_threshold);
 }
 typedef void (*shade_fn)(SceneD, CamD, PoolD, CountersD*, uint64_t);
@@ -684,7 +837,7 @@ void launch_math_probe(int which, const double* in, uint32_t n, double* out, hip
 }
 int kernel_occupancy_blocks(int which, int variant) {
     int nb = 0;
-    const void* f = which == 0 ? (variant > 0 ? (const void*)k_extend_fetch : (const void*)k_extend) : (const void*)pick_shade(variant);
+    const void* f = which == 0 ? (variant > 0 ? (const void*)k_extend_fetch : variant < 0 ? (const void*)k_extend : (const void*)k_extend2) : (const void*)pick_shade(variant);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

@@ -268,14 +268,14 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     if (const char* e = getenv("PT_GRID_MULT")) mult = std::max(1, atoi(e));
     int shade_variant = 12;   // k_shade<sort, min waves/SIMD>: sort*10 + waves (12 = windowed material sort, 2 = plain)
     if (const char* e = getenv("PT_SHADE_VARIANT")) shade_variant = atoi(e);
-    int fetch_threshold = 0;
-    if (const char* e = getenv("PT_FETCH_THRESHOLD")) fetch_threshold = std::min(64, std::max(0, atoi(e)));
+    int fetch_threshold = s->n_mesh_entries > 0 ? 0 : -1;   // two-phase K2 pays only when there are meshes to defer
+    if (const char* e = getenv("PT_FETCH_THRESHOLD")) fetch_threshold = std::min(64, std::max(-1, atoi(e)));
     const int blocks_extend = kernel_occupancy_blocks(0, fetch_threshold), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;
-    // K2 variant (fetch_threshold): 0 = batch kernel (default); n in 1..64 = persistent dynamic-fetch
-    // kernel that refills a wave when >= n of its 64 lanes are idle (experimental)
+    // K2 variant (PT_FETCH_THRESHOLD): 0 = two-phase kernel (default with meshes); -1 = batch kernel (default without); n in 1..64 =
+    // persistent dynamic-fetch kernel refilling a wave when >= n lanes are idle (experimental)
     CountersD init_cnt;
     memset(&init_cnt, 0, sizeof init_cnt);
     init_cnt.alive = spp == 0 ? 0 : n_slots;   // every slot starts with one sample (k <= spp / n_slots <= total_work)

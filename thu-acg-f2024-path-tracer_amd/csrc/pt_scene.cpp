@@ -578,6 +578,8 @@ int pt::scene_build(pt_scene* s) {
     v.n_lights = (uint32_t)lights.size();
     dev.view = v;
     s->n_prims = v.n_prims;
+    s->n_mesh_entries = 0;
+    for (const Entry& e : entries) s->n_mesh_entries += e.kind == ENTRY_MESH ? 1u : 0u;
     s->built = true;
     return 0;
 }

@@ -60,6 +60,7 @@ struct pt_scene {
     std::map<std::string, int> images;   // registered image name -> texture handle
     bool built = false;
     uint32_t n_prims = 0;
+    uint32_t n_mesh_entries = 0;   // world-level triangle meshes (picks the K2 variant)
     pt::DeviceBuffers dev;
     // path pool cache (re-used across pt_render calls of the same size)
     void* pool_mem = nullptr;
