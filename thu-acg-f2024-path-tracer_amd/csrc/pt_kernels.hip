@@ -18,6 +18,12 @@ namespace pt {
 
 constexpr int BLOCK = 256;
 
+// K2 streams the rays in and the hits out once and never re-reads them, while the scene tables
+// (BVH, primitives: a few MB) are re-read by every wave: non-temporal accesses keep the stream from
+// evicting the scene out of the 4 MB-per-XCD L2. (K3 re-reads its window, so it uses plain accesses.)
+template <class T> PT_DEV T ldnt(const T* p) { return __builtin_nontemporal_load(p); }
+template <class T> PT_DEV void stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
 // ---------------------------------------------------------------------------------------
 // Closest-hit traversal. Two-level BVH2 walked with one per-lane stack held in LDS
 // (stack[level][lane]: a wave touches 64 consecutive dwords per level -> conflict free).
@@ -39,9 +45,10 @@ PT_DEV void consider(Closest& best, double t, uint32_t id) {
 // oif = fl32(o/d) and t' = fma32(b, idf, -oif) for a box bound b. Error analysis (u = 2^-24):
 //   t' = (b*id*(1+da) - oi*(1+db))*(1+dc)  =>  |t' - t| <= 2u (|b||id| + |oi|) <= 2u (S|id| + |oi|)
 // with S = max |coordinate| of the boxes of the tree being walked (SceneD::tlas_extent /
-// Entry::extent). Every axis interval is widened by e = 4u (S|id| + |oi|) — twice the bound, which
-// also covers the rounding of e itself and of the +-e — so a box the exact ray touches inside
-// [t_min, t_best] is never rejected. 1/d is clamped to +-1e30 so that an exactly axis-parallel ray
+// Entry::extent). 1/d itself is a fast f32 reciprocal of fl32(d) (<= 3u relative error: the slabs
+// of a ray tilted by 3u, another 3u (S|id| + |oi|)). Every axis interval is widened by
+// e = 8u (S|id| + |oi|), which also covers the rounding of e itself and of the +-e — so a box the
+// exact ray touches inside [t_min, t_best] is never rejected. 1/d is clamped to +-1e30 so that an exactly axis-parallel ray
 // (they occur: a direction sampled inside the plane of an axis-aligned light has d.y == 0) yields
 // finite products: the axis then behaves as "parallel" — everything when the origin is inside the
 // slab, nothing when it is outside. Box tests never influence WHICH hit wins, only how much work
@@ -50,11 +57,14 @@ struct RayF {
     float idx, idy, idz, oix, oiy, oiz, ex, ey, ez;
 };
 PT_DEV void rayf_axis(double o, double d, float S, float& idf, float& oif, float& e) {
-    double id = 1.0 / d;
-    if (!(fabs(id) <= 1e30)) id = __builtin_copysign(1e30, d);
-    idf = (float)id;
-    oif = (float)(o * id);
-    e = (S * fabsf(idf) + fabsf(oif)) * 2.3841858e-07f;   // 4u
+    // idf: f32 reciprocal of fl32(d) (relative error <= 3u against 1/d), clamped to +-1e30; the slab
+    // parameters are then those of a ray whose direction differs by <= 3u — absorbed by the margin
+    float df = (float)d;
+    float id = __frcp_rn(df);
+    if (!(fabsf(id) <= 1e30f)) id = copysignf(1e30f, df);
+    idf = id;
+    oif = (float)(o * (double)id);
+    e = (S * fabsf(id) + fabsf(oif)) * 4.7683716e-07f;   // 8u >= (2u arithmetic + 3u reciprocal) with slack
 }
 PT_DEV RayF make_rayf(V3 o, V3 d, float S) {
     RayF f;
@@ -121,7 +131,8 @@ template <bool F32>
 PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uint32_t* stk /* &stack[0][lane] */) {
     Closest best{D_INF, HIT_NONE};
     RayD r = wray;
-    RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
+    const RayF fw = make_rayf(wray.o, wray.d, sc.tlas_extent);   // world-space reduction, kept across instances
+    RayF f = fw;
     V3 inv{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};   // f64 variant only
     const float t_min_f = __double2float_rd(t_min);
     float t_max_f = t_max_f32(best.t);
@@ -162,7 +173,7 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
             if (e.kind == ENTRY_MESH) {
                 r = lr;
                 f = make_rayf(r.o, r.d, e.extent);
-                inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
+                if (!F32) inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
                 if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = REF_LEAVE_INSTANCE;
                 cur = e.blas_root;
                 continue;
@@ -172,8 +183,8 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
             t_max_f = t_max_f32(best.t);
         } else if (cur == REF_LEAVE_INSTANCE) {
             r = wray;
-            f = make_rayf(r.o, r.d, sc.tlas_extent);
-            inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
+            f = fw;
+            if (!F32) inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
         }
         if (sp == 0) break;
         cur = stk[(--sp) * BLOCK];
@@ -240,10 +251,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
     unsigned long long nseg = 0;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
         if (pool.bounce[s] >= SLOT_IDLE) continue;
-        RayD r{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
+        RayD r{V3{ldnt(&pool.ox[s]), ldnt(&pool.oy[s]), ldnt(&pool.oz[s])}, V3{ldnt(&pool.dx[s]), ldnt(&pool.dy[s]), ldnt(&pool.dz[s])}, ldnt(&pool.time[s])};
         Closest c = closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
-        pool.hit_t[s] = c.t;
-        pool.hit_prim[s] = c.id;
+        stnt(&pool.hit_t[s], c.t);
+        stnt(&pool.hit_prim[s], (uint32_t)(c.id));
         ++nseg;
     }
     if (nseg) atomicAdd(&cnt->segments, nseg);
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend2(SceneD sc, PoolD pool, Counte
             uint32_t n_my = 0;
             if (alive) {
                 ++nseg;
-                const RayD r{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, pool.time[slot]};
+                const RayD r{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, ldnt(&pool.time[slot])};
                 const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
                 Closest best{D_INF, HIT_NONE};
                 float t_max_f = t_max_f32(best.t);
@@ -356,8 +367,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend2(SceneD sc, PoolD pool, Counte
                     cur = stk[(--sp) * BLOCK];
                 }
                 if (n_my == 0) {
-                    pool.hit_t[slot] = best.t;
-                    pool.hit_prim[slot] = best.id;
+                    stnt(&pool.hit_t[slot], best.t);
+                    stnt(&pool.hit_prim[slot], (uint32_t)(best.id));
                 } else {
                     s_best_t[sl] = (unsigned long long)__double_as_longlong(best.t);
                     s_best_id[sl] = best.id;
@@ -385,15 +396,15 @@ __global__ __launch_bounds__(BLOCK) void k_extend2(SceneD sc, PoolD pool, Counte
             const uint32_t idx = g * 64u + (uint32_t)lane;
             if (idx < n_rays) {
                 const uint32_t sl = s_rays[idx], slot = wbase + sl;
-                const RayD r{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, pool.time[slot]};
+                const RayD r{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, ldnt(&pool.time[slot])};
                 Closest best{__longlong_as_double((long long)s_best_t[sl]), s_best_id[sl]};
                 const uint32_t n_my = s_nitems[sl];
                 for (uint32_t k = 0; k < n_my; ++k) {
                     const Entry e = sc.entries[s_items[sl * EXT_MAXI + k]];
                     blas_pass(sc, r, e, t_min, t_min_f, stk, EXT_STACK, best);
                 }
-                pool.hit_t[slot] = best.t;
-                pool.hit_prim[slot] = best.id;
+                stnt(&pool.hit_t[slot], best.t);
+                stnt(&pool.hit_prim[slot], (uint32_t)(best.id));
             }
         }
         __syncthreads();   // LDS lists are reused by the next window
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
                 const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (idx < cursor_end && pool.bounce[idx] < SLOT_IDLE) {
                     slot = (uint32_t)idx;
-                    r = RayD{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, pool.time[slot]};
+                    r = RayD{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, ldnt(&pool.time[slot])};
                     f = make_rayf(r.o, r.d, sc.tlas_extent);
                     best = Closest{D_INF, HIT_NONE};
                     t_max_f = t_max_f32(best.t);
@@ -489,13 +500,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
                 t_max_f = t_max_f32(best.t);
             }
         } else if (cur == REF_LEAVE_INSTANCE) {                   // back to world space: reload the ray
-            r = RayD{V3{pool.ox[slot], pool.oy[slot], pool.oz[slot]}, V3{pool.dx[slot], pool.dy[slot], pool.dz[slot]}, r.time};
+            r = RayD{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, r.time};
             f = make_rayf(r.o, r.d, sc.tlas_extent);
         }
         if (pop) {
             if (sp == 0) {
-                pool.hit_t[slot] = best.t;
-                pool.hit_prim[slot] = best.id;
+                stnt(&pool.hit_t[slot], best.t);
+                stnt(&pool.hit_prim[slot], (uint32_t)(best.id));
                 active = false;
             } else {
                 cur = stk[(--sp) * BLOCK];

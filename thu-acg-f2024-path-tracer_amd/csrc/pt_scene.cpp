@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/pt_amd.h"
@@ -520,7 +521,9 @@ int pt::scene_build(pt_scene* s) {
             std::vector<uint32_t> perm;
             const uint32_t tri_base = (uint32_t)tris.size();
             if ((size_t)tri_base + o->tris.size() > 0x07FFFFFFu) return set_error("pt_world_build: too many triangles");
-            Builder bl{nodes, items, 4, MAX_BLAS_DEPTH, true, &perm, tri_base};
+            int leaf_max = 4;   // PT_LEAF_MAX: experiments only (smaller leaves were slower on scene 6)
+            if (const char* e = getenv("PT_LEAF_MAX")) leaf_max = std::min(8, std::max(1, atoi(e)));
+            Builder bl{nodes, items, leaf_max, MAX_BLAS_DEPTH, true, &perm, tri_base};
             Box bb;
             e.blas_root = bl.build(0, items.size(), 0, bb);
             max_blas_depth = std::max(max_blas_depth, bl.depth_reached);
