@@ -153,11 +153,13 @@ def main():
         ms_ext = sum(s["ms_extend"] for s in stats); ms_sh = sum(s["ms_shade"] for s in stats)
         n_ext = sum(s["launches_extend"] for s in stats); n_sh = sum(s["launches_shade"] for s in stats)
         my_seg = sum(s["segments"] for s in stats); my_smp = sum(s["samples"] for s in stats)
+        ext_name = {0: "k_extend2", 1: "k_extend", 2: "k_extend_fetch"}.get(stats[0]["extend_variant"], "k_extend")
+        sh_name = f"k_shade<{'true' if stats[0]['shade_variant'] >= 10 else 'false'}, {stats[0]['shade_variant'] % 10}>"
         if ms_ext >= ms_sh:
-            kname, kms, kn = "k_extend", ms_ext, n_ext
+            kname, kms, kn = ext_name, ms_ext, n_ext
             bytes_total = my_seg * B_EXTEND_PER_SEGMENT
         else:
-            kname, kms, kn = "k_shade", ms_sh, n_sh
+            kname, kms, kn = sh_name, ms_sh, n_sh
             bytes_total = my_seg * B_SHADE_PER_SEGMENT + my_smp * B_FB_PER_SAMPLE
         avg_ms = kms / max(kn, 1)
         achieved = (bytes_total / max(kn, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -165,15 +167,15 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get(kname, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc_path)).get("k_extend" if ms_ext >= ms_sh else "k_shade", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel": kname,
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(kn),
                     "algorithmic_bytes_per_launch": round(bytes_total / max(kn, 1), 1),
-                    "other_kernel": {"name": "k_shade" if kname == "k_extend" else "k_extend",
-                                     "avg_launch_ms": round((ms_sh if kname == "k_extend" else ms_ext) / max(n_sh if kname == "k_extend" else n_ext, 1), 5)},
+                    "other_kernel": {"name": sh_name if ms_ext >= ms_sh else ext_name,
+                                     "avg_launch_ms": round((ms_sh if ms_ext >= ms_sh else ms_ext) / max(n_sh if ms_ext >= ms_sh else n_ext, 1), 5)},
                     "whole_pipeline_GBps": round((my_seg * (B_EXTEND_PER_SEGMENT + B_SHADE_PER_SEGMENT) + my_smp * B_FB_PER_SAMPLE) / max((ms_ext + ms_sh) * 1e-3, 1e-9) / 1e9, 3)}
         out = {
             "metric": "Msamples/s (WxHxspp/s), scene 6 FHD@4000spp" if (args.scene, args.width, args.spp) == (6, 1920, 4000) else "Msamples/s (WxHxspp/s)",

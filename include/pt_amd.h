@@ -53,7 +53,8 @@ typedef struct pt_render_stats {
     double ms_total;                       /* wall time inside pt_render (host clock, synced) */
     double ms_extend, ms_shade, ms_other;  /* HIP-event time per kernel family (profile=1) */
     uint64_t launches_extend, launches_shade;
-    uint32_t vgpr_extend, vgpr_shade, blocks_extend, blocks_shade;
+    uint32_t extend_variant, shade_variant;   /* K2: 0 two-phase k_extend2, 1 batch k_extend, 2 dynamic-fetch; K3: sort*10 + min waves/SIMD */
+    uint32_t blocks_extend, blocks_shade;
 } pt_render_stats;
 
 const char* pt_last_error(void);

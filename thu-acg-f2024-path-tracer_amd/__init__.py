@@ -72,8 +72,8 @@ class RenderStats(C.Structure):
         ("ms_other", C.c_double),
         ("launches_extend", C.c_uint64),
         ("launches_shade", C.c_uint64),
-        ("vgpr_extend", C.c_uint32),
-        ("vgpr_shade", C.c_uint32),
+        ("extend_variant", C.c_uint32),
+        ("shade_variant", C.c_uint32),
         ("blocks_extend", C.c_uint32),
         ("blocks_shade", C.c_uint32),
     ]

@@ -352,6 +352,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         stats->ms_other = timer.ms[2];
         stats->launches_extend = timer.launches[0];
         stats->launches_shade = timer.launches[1];
+        stats->extend_variant = fetch_threshold == 0 ? 0u : fetch_threshold < 0 ? 1u : 2u;
+        stats->shade_variant = (uint32_t)shade_variant;
         stats->blocks_extend = (uint32_t)grid_extend;
         stats->blocks_shade = (uint32_t)grid_shade;
     }
