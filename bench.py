@@ -91,13 +91,15 @@ def main():
         args.gpus = world
     dist = None
     torch = None
-    if world > 1:
+    force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"     # exercise the N>1 code path with one rank (1-GPU boxes)
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     import parallel_spp
 
@@ -110,16 +112,17 @@ def main():
     height = pt.image_height(cam)
     lo, hi = parallel_spp.shard_range(args.spp, rank, world)
     n_pix = args.width * height
-    dev_accum = torch.zeros((height, args.width, 3), dtype=torch.float64, device="cuda") if world > 1 else None
+    use_dist = world > 1 or force_dist
+    dev_accum = torch.zeros((height, args.width, 3), dtype=torch.float64, device="cuda") if use_dist else None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     def step(profile):
         acc, st = scene.render(cam, args.seed, lo, hi, slots_per_pixel=args.slots_per_pixel, profile=profile)
-        if world > 1:
+        if use_dist:
             dev_accum.copy_(torch.from_numpy(acc))
             parallel_spp.reduce_accum_to_root(dev_accum)     # the single RCCL collective of the frame
             torch.cuda.synchronize()
@@ -135,7 +138,7 @@ def main():
         stats.append(st.as_dict())
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -194,7 +197,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.cpu_seconds, images)
             out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -308,3 +308,30 @@ def test_cornell_1920_square_properties(pt, ctx):
     assert a.shape == (1920, 1920, 3) and st.samples == 1920 * 1920
     assert np.isfinite(a).all() and 3.0 < st.segments / st.samples < 4.5
     gs.close()
+
+
+def test_cli_renders_scene3_like_the_reference_binary(pt, det, ctx, tmp_path):
+    """host/main.cpp: the reference's `-s 3` with explicit size overrides; the PNG must be the
+    oracle's gamma-quantised image (camera.rs:109-123) for the same seed, up to the summation order
+    of the default dynamic schedule (which can move a value across a u8 boundary only by rounding
+    of the last bits: allow <= 1 level on a handful of bytes)."""
+    import subprocess
+    from PIL import Image
+
+    exe = os.path.join(os.path.dirname(pt.LIB_PATH), "pt_render")
+    out = str(tmp_path / "cornell.png")
+    r = subprocess.run([exe, "-s", "3", "--width", "96", "--spp", "8", "--seed", "5", "--out", out, "--assets", pt.ASSET_DIR],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "rendering production" in r.stderr and "as_secs_f64" in r.stderr      # camera.rs:101,125
+    img = np.asarray(Image.open(out).convert("RGB")).astype(int)
+    os_ = det.Scene()
+    ocam = os_.build_scene(3, 96, 8)
+    oa, _ = os_.render(ocam, 5, 0, 8)
+    want = det.resolve_u8(oa, 8).astype(int)
+    assert img.shape == want.shape
+    diff = np.abs(img - want)
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    bad = subprocess.run([exe, "-s", "5", "--width", "32", "--spp", "1", "--assets", "/nonexistent"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 101 and "panic" in bad.stderr                         # asset errors are fatal like unwrap()
+    os_.close()
