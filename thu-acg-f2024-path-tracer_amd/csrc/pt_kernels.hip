@@ -273,8 +273,9 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 // dense waves whose lanes all do the same kind of work. The closest hit is order-independent
 // (minimum t, ties -> larger id), so the result is bit-identical to the batch kernel's.
 // ---------------------------------------------------------------------------------------
-// EXT_STACK covers top-level depth + 1 + mesh depth (<= 10 + 1 + 20, enforced by the host builder)
-constexpr int EXT_WINDOW = 1024, EXT_STACK = 32, EXT_MAXI = 4;
+// EXT_STACK = 24 entries keeps the block at 47 KB of LDS (3 blocks per CU); the host only selects this
+// kernel for scenes whose BVHs need <= 24 (pt_scene::stack_need), deeper scenes use the batch kernel.
+constexpr int EXT_WINDOW = 1024, EXT_STACK = 24, EXT_MAXI = 4;
 
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
     RayD r = wray;
@@ -306,7 +307,7 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
 }
 
 __global__ __launch_bounds__(BLOCK) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
-    __shared__ uint32_t stack[EXT_STACK * BLOCK];                 // 32 KB
+    __shared__ uint32_t stack[EXT_STACK * BLOCK];                 // 24 KB
     __shared__ unsigned long long s_best_t[EXT_WINDOW];            //  8 KB  (bit pattern of the f64 t)
     __shared__ uint32_t s_best_id[EXT_WINDOW];                     //  4 KB
     __shared__ uint16_t s_items[EXT_WINDOW * EXT_MAXI];            //  8 KB  recorded mesh entries per ray

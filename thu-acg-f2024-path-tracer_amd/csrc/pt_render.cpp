@@ -268,8 +268,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     if (const char* e = getenv("PT_GRID_MULT")) mult = std::max(1, atoi(e));
     int shade_variant = 12;   // k_shade<sort, min waves/SIMD>: sort*10 + waves (12 = windowed material sort, 2 = plain)
     if (const char* e = getenv("PT_SHADE_VARIANT")) shade_variant = atoi(e);
-    int fetch_threshold = s->n_mesh_entries > 0 ? 0 : -1;   // two-phase K2 pays only when there are meshes to defer
+    // two-phase K2 pays only when there are meshes to defer, and its short LDS stack must fit the scene's BVHs
+    int fetch_threshold = (s->n_mesh_entries > 0 && s->stack_need <= (uint32_t)EXTEND2_STACK_ENTRIES) ? 0 : -1;
     if (const char* e = getenv("PT_FETCH_THRESHOLD")) fetch_threshold = std::min(64, std::max(-1, atoi(e)));
+    if (fetch_threshold == 0 && s->stack_need > (uint32_t)EXTEND2_STACK_ENTRIES) fetch_threshold = -1;
     const int blocks_extend = kernel_occupancy_blocks(0, fetch_threshold), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 

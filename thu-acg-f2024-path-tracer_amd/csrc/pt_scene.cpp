@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -552,6 +553,8 @@ int pt::scene_build(pt_scene* s) {
     Box wb;
     uint32_t tlas_root = tl.build(0, tlas_items.size(), 0, wb);
     if (tl.depth_reached + 1 + max_blas_depth + 1 > TRAVERSAL_STACK) return set_error("pt_world_build: BVH too deep for the traversal stack");
+    s->stack_need = (uint32_t)(tl.depth_reached + 1 + max_blas_depth + 1);
+    if (getenv("PT_VERBOSE")) fprintf(stderr, "[pt] BVH: top-level depth %d, deepest mesh tree %d, %zu nodes, %zu triangles\n", tl.depth_reached, max_blas_depth, nodes.size(), tris.size());
 
     // texture atlas
     std::vector<TexD> tex(s->tex.size());
