@@ -306,10 +306,8 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
+__global__ __launch_bounds__(BLOCK, 4) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
     __shared__ uint32_t stack[EXT_STACK * BLOCK];                 // 24 KB
-    __shared__ unsigned long long s_best_t[EXT_WINDOW];            //  8 KB  (bit pattern of the f64 t)
-    __shared__ uint32_t s_best_id[EXT_WINDOW];                     //  4 KB
     __shared__ uint16_t s_items[EXT_WINDOW * EXT_MAXI];            //  8 KB  recorded mesh entries per ray
     __shared__ uint8_t s_nitems[EXT_WINDOW];
     __shared__ uint16_t s_rays[EXT_WINDOW];                        // rays with recorded meshes
@@ -370,9 +368,9 @@ __global__ __launch_bounds__(BLOCK) void k_extend2(SceneD sc, PoolD pool, Counte
                 if (n_my == 0) {
                     stnt(&pool.hit_t[slot], best.t);
                     stnt(&pool.hit_prim[slot], (uint32_t)(best.id));
-                } else {
-                    s_best_t[sl] = (unsigned long long)__double_as_longlong(best.t);
-                    s_best_id[sl] = best.id;
+                } else {   // phase-A best parked in the pool (plain store: re-read by phase B of this block)
+                    pool.hit_t[slot] = best.t;
+                    pool.hit_prim[slot] = best.id;
                     s_nitems[sl] = (uint8_t)n_my;
                 }
             }
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend2(SceneD sc, PoolD pool, Counte
             if (idx < n_rays) {
                 const uint32_t sl = s_rays[idx], slot = wbase + sl;
                 const RayD r{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, ldnt(&pool.time[slot])};
-                Closest best{__longlong_as_double((long long)s_best_t[sl]), s_best_id[sl]};
+                Closest best{pool.hit_t[slot], pool.hit_prim[slot]};
                 const uint32_t n_my = s_nitems[sl];
                 for (uint32_t k = 0; k < n_my; ++k) {
                     const Entry e = sc.entries[s_items[sl * EXT_MAXI + k]];
