@@ -200,6 +200,43 @@ def test_random_scenes_bit_exact(pt, det, ctx, seed):
     gs.close(); os_.close()
 
 
+def _all_light_kinds_scene():
+    """Lights list holding every kind of Hittable the reference can put there (world.rs:18-20):
+    quad, sphere, cuboid, triangle mesh, and instanced quad / cuboid / mesh / sphere."""
+    spec = SceneSpec()
+    lm = lambda r, g, b: spec.add("mat_light", spec.add("tex_solid_rgb", r, g, b))
+    white = spec.add("mat_diffuse", spec.add("tex_solid_rgb", 0.7, 0.7, 0.7), -1)
+    metal = spec.add("mat_metal", spec.add("tex_solid_rgb", 0.9, 0.8, 0.6), spec.add("tex_solid_f", 0.2))
+    spec.add("world_add_object", spec.add("quad", (-10.0, 0.0, -10.0), (0.0, 0.0, 20.0), (20.0, 0.0, 0.0), white))
+    spec.add("world_add_object", spec.add("sphere", 0.7, (0.0, 0.7, 0.0), (0.0, 0.7, 0.0), metal))
+    spec.add("world_add_object", spec.add("instance", spec.add("cuboid", (0.0, 0.0, 0.0), (0.8, 1.2, 0.8), white), (0.0, 1.0, 0.0), 0.4, (1.5, 0.0, 0.5)))
+    P, I = icosphere(0)
+    spec.add("world_add_light", spec.add("quad", (-1.0, 4.0, -1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), lm(6, 6, 5)))
+    spec.add("world_add_light", spec.add("sphere", 0.25, (-2.5, 2.0, 1.0), (-2.5, 2.0, 1.0), lm(9, 4, 2)))
+    spec.add("world_add_light", spec.add("cuboid", (2.5, 1.0, -1.0), (2.9, 1.4, -0.6), lm(2, 7, 3)))
+    spec.add("world_add_light", spec.add("mesh", 0.3, P, I, None, None, lm(3, 3, 9)))
+    spec.add("world_add_light", spec.add("instance", spec.add("quad", (0.0, 0.0, 0.0), (0.6, 0.0, 0.0), (0.0, 0.6, 0.0), lm(5, 5, 5)), (0.0, 1.0, 0.0), 0.8, (-1.5, 0.5, -2.0)))
+    spec.add("world_add_light", spec.add("instance", spec.add("cuboid", (0.0, 0.0, 0.0), (0.3, 0.3, 0.3), lm(4, 1, 4)), (1.0, 0.0, 0.0), -0.5, (0.5, 2.5, 2.0)))
+    spec.add("world_add_light", spec.add("instance", spec.add("mesh", 0.25, P, I, None, None, lm(1, 6, 6)), (0.0, 0.0, 1.0), 1.1, (2.0, 2.5, 1.5)))
+    spec.add("world_add_light", spec.add("instance", spec.add("sphere", 0.2, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), lm(8, 8, 1)), (0.0, 1.0, 0.0), 0.0, (-0.5, 1.8, -1.5)))
+    spec.add("world_build")
+    spec.camera = default_camera(width=56, env_color=(0.02, 0.02, 0.03))
+    return spec
+
+
+def test_lights_of_every_kind_bit_exact(pt, det, ctx):
+    spec = _all_light_kinds_scene()
+    gs, os_ = pt.Scene(ctx), det.Scene()
+    gres, ores = spec.replay(gs), spec.replay(os_)
+    assert gs.prim_count() == os_.prim_count() == 1 + 1 + 6 + 1 + 1 + 6 + 20 + 1 + 6 + 20 + 1
+    ga, st = gs.render(spec.make_camera(pt.Camera, gres), 11, 0, 6, slots_per_pixel=1)
+    oa, cnt = os_.render(spec.make_camera(det.Camera, ores), 11, 0, 6)
+    assert st.segments == cnt["segments"]
+    np.testing.assert_array_equal(ga, oa)      # incl. the NaN/inf the reference's Sphere::pdf produces on the light itself
+    assert np.isfinite(ga).mean() > 0.8 and np.nanmax(ga[np.isfinite(ga)]) > 0
+    gs.close(); os_.close()
+
+
 def test_mesh_with_normals_uvs_image_textures_and_normal_map(pt, det, ctx):
     rng = np.random.default_rng(5)
     img = rng.integers(0, 256, (16, 32, 3), dtype=np.uint8)

@@ -146,45 +146,120 @@ PT_DEV bool reconstruct_hit(const SceneD& sc, const RayD& world_ray, uint32_t gi
     return true;
 }
 
-// ---- lights list: HittableList::sample / pdf (list.rs:78-96) over quads and spheres -------
-PT_DEV V3 lights_sample(const SceneD& sc, V3 origin, double time, Rng& rng) {
-    uint32_t i = rng_index(rng, sc.n_lights);
-    const Entry e = sc.entries[sc.lights[i]];
-    const PrimRef pr = sc.prims[e.first_prim];
+// ---- lights list: Hittable::sample / pdf for every kind of object (list.rs:78-96, quad.rs:80-98,
+// sphere.rs:110-135, mesh.rs:122-141, cuboid.rs:78-84, instance.rs:64-75) ---------------------------
+PT_DEV V3 sample_quad_dir(const QuadD& q, V3 origin, Rng& rng) {                  // quad.rs:80-86
     double a = rng_f64(rng), b = rng_f64(rng);
-    if (e.kind == ENTRY_QUAD) {                               // quad.rs:80-86
-        const QuadD& q = sc.quads[pr.index];
-        V3 point = ld3(q.q) + ld3(q.u) * a + ld3(q.v) * b;
-        return normalize(point - origin);
-    }
-    const SphereD& s = sc.spheres[pr.index];                  // sphere.rs:110-122
-    double theta = 2.0 * D_PI * a;
-    double phi = detmath::acos(2.0 * b - 1.0);
-    double x = detmath::sin(phi) * detmath::cos(theta), y = detmath::sin(phi) * detmath::sin(theta), z = detmath::cos(phi);
-    V3 center = ld3(s.p1) + (ld3(s.p2) - ld3(s.p1)) * time;
-    V3 point = center + V3{x, y, z} * s.r;
+    V3 point = ld3(q.q) + ld3(q.u) * a + ld3(q.v) * b;
     return normalize(point - origin);
 }
-PT_DEV double lights_pdf(const SceneD& sc, V3 origin, V3 direction, double time) {
-    if (sc.n_lights == 0) return 0.0;
+PT_DEV double pdf_quad(const SceneD& sc, const QuadD& q, uint32_t mat, V3 origin, V3 direction, double time) {   // quad.rs:88-98
     RayD r = make_ray(origin, direction, time);
+    double t, al, be;
+    if (!hit_quad(q, r, 0.0, t, al, be)) return 0.0;
+    HitD h;
+    finish_hit(sc, r, ray_at(r, t), ld3(q.n), t, mat, al, be, h);
+    double area = length(cross(ld3(q.u), ld3(q.v)));
+    double cos_theta = fabs(dot(r.d, h.sn));
+    return (h.dist * h.dist) / (cos_theta * area);
+}
+PT_DEV V3 lights_sample(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
+    uint32_t i = rng_index(rng, sc.n_lights);
+    const Entry e = sc.entries[sc.lights[i]];
+    V3 origin = origin_w;
+    if (e.inst >= 0) {                                                            // instance.rs:64-66
+        const InstD& m = sc.insts[e.inst];
+        origin = xform_point(m.i0, m.i1, m.i2, m.it, origin_w);
+    }
+    V3 dir;
+    if (e.kind == ENTRY_QUAD) {
+        dir = sample_quad_dir(sc.quads[sc.prims[e.first_prim].index], origin, rng);
+    } else if (e.kind == ENTRY_CUBOID) {                                          // cuboid.rs:78-80 -> list.rs:78-84
+        uint32_t j = rng_index(rng, 6u);
+        dir = sample_quad_dir(sc.quads[sc.prims[e.first_prim + j].index], origin, rng);
+    } else if (e.kind == ENTRY_MESH) {                                            // mesh.rs:207-209 -> :122-129
+        uint32_t j = rng_index(rng, e.n_prims);
+        const TriD& tr = sc.tris[sc.prims[e.first_prim + j].index];
+        double u = rng_f64(rng), v = rng_f64(rng);
+        double w = 1.0 - u - v;
+        V3 point = ld3(tr.v0) * w + ld3(tr.v1) * u + ld3(tr.v2) * v;
+        dir = normalize(point - origin);
+    } else {                                                                      // sphere.rs:110-122
+        const SphereD& s = sc.spheres[sc.prims[e.first_prim].index];
+        double a = rng_f64(rng), b = rng_f64(rng);
+        double theta = 2.0 * D_PI * a;
+        double phi = detmath::acos(2.0 * b - 1.0);
+        double sp, cp, st, ct;
+        detmath::sincos(phi, sp, cp);
+        detmath::sincos(theta, st, ct);
+        V3 center = ld3(s.p1) + (ld3(s.p2) - ld3(s.p1)) * time;
+        V3 point = center + V3{sp * ct, sp * st, cp} * s.r;
+        dir = normalize(point - origin);
+    }
+    if (e.inst >= 0) {                                                            // instance.rs:67-68 (not re-normalised)
+        const InstD& m = sc.insts[e.inst];
+        dir = xform_vector(m.c0, m.c1, m.c2, dir);
+    }
+    return dir;
+}
+PT_DEV double lights_pdf(const SceneD& sc, V3 origin_w, V3 direction_w, double time) {
+    if (sc.n_lights == 0) return 0.0;
     double sum = 0.0;
     for (uint32_t i = 0; i < sc.n_lights; ++i) {
         const Entry e = sc.entries[sc.lights[i]];
-        const PrimRef pr = sc.prims[e.first_prim];
+        V3 origin = origin_w, direction = direction_w;
+        if (e.inst >= 0) {                                                        // instance.rs:71-75
+            const InstD& m = sc.insts[e.inst];
+            origin = xform_point(m.i0, m.i1, m.i2, m.it, origin_w);
+            direction = xform_vector(m.i0, m.i1, m.i2, direction_w);
+        }
         double pdf = 0.0;
-        if (e.kind == ENTRY_QUAD) {                           // quad.rs:88-98 (interval [0, inf])
-            const QuadD& q = sc.quads[pr.index];
-            double t, al, be;
-            if (hit_quad(q, r, 0.0, t, al, be)) {
-                HitD h;
-                finish_hit(sc, r, ray_at(r, t), ld3(q.n), t, pr.mat, al, be, h);
-                double area = length(cross(ld3(q.u), ld3(q.v)));
-                double cos_theta = fabs(dot(r.d, h.sn));
-                pdf = (h.dist * h.dist) / (cos_theta * area);
+        if (e.kind == ENTRY_QUAD) {
+            const PrimRef pr = sc.prims[e.first_prim];
+            pdf = pdf_quad(sc, sc.quads[pr.index], pr.mat, origin, direction, time);
+        } else if (e.kind == ENTRY_CUBOID) {                                      // list.rs:86-96 over the six sides
+            double s6 = 0.0;
+            for (uint32_t j = 0; j < 6u; ++j) {
+                const PrimRef pr = sc.prims[e.first_prim + j];
+                s6 += pdf_quad(sc, sc.quads[pr.index], pr.mat, origin, direction, time);
             }
-        } else {                                              // sphere.rs:124-135
-            const SphereD& s = sc.spheres[pr.index];
+            pdf = s6 / 6.0;
+        } else if (e.kind == ENTRY_MESH) {                                        // list.rs:86-96 over ALL triangles (O(n), like the reference)
+            double sn = 0.0;
+            RayD r = make_ray(origin, direction, time);
+            for (uint32_t j = 0; j < e.n_prims; ++j) {
+                const PrimRef pr = sc.prims[e.first_prim + j];
+                const TriD& tr = sc.tris[pr.index];
+                double t, u, v, p = 0.0;
+                if (hit_tri(tr, r, 0.0, t, u, v)) {                               // mesh.rs:131-141
+                    V3 v0 = ld3(tr.v0);
+                    V3 edge1 = ld3(tr.v1) - v0, edge2 = ld3(tr.v2) - v0;
+                    double w = 1.0 - u - v;
+                    V3 normal;
+                    double tu = u, tv = v;
+                    if (pr.kind & PRIM_HAS_NORMALS) {
+                        const TriAttr& at = sc.tri_attr[pr.index];
+                        normal = normalize(ld3(at.n[0]) * w + ld3(at.n[1]) * u + ld3(at.n[2]) * v);
+                    } else {
+                        normal = normalize(cross(edge1, edge2));
+                    }
+                    if (pr.kind & PRIM_HAS_UVS) {
+                        const TriAttr& at = sc.tri_attr[pr.index];
+                        tu = at.uv[0][0] * w + at.uv[1][0] * u + at.uv[2][0] * v;
+                        tv = at.uv[0][1] * w + at.uv[1][1] * u + at.uv[2][1] * v;
+                    }
+                    HitD h;
+                    finish_hit(sc, r, ray_at(r, t), normal, t, pr.mat, tu, tv, h);
+                    double area = 0.5 * length(cross(edge1, edge2));
+                    double cos_theta = fabs(dot(direction, h.sn));            // `direction`, not the normalised ray (mesh.rs:136)
+                    p = h.dist * h.dist / (cos_theta * area);
+                }
+                sn += p;
+            }
+            pdf = sn / (double)e.n_prims;
+        } else {                                                                  // sphere.rs:124-135
+            const SphereD& s = sc.spheres[sc.prims[e.first_prim].index];
+            RayD r = make_ray(origin, direction, time);
             double t;
             V3 c;
             if (hit_sphere(s, r, 0.0, t, c)) {

@@ -482,11 +482,7 @@ int pt::scene_build(pt_scene* s) {
             o = &s->objs[top->child];
         }
         const bool is_light = wi < s->world_lights.size();
-        if (is_light) {
-            if (inst >= 0 || (o->kind != OBJ_SPHERE && o->kind != OBJ_QUAD))
-                return set_error("pt_world_add_light: only un-instanced quads and spheres can be sampled as lights in this build");
-            lights.push_back((uint32_t)entries.size());
-        }
+        if (is_light) lights.push_back((uint32_t)entries.size());   // any hittable may be a light (world.rs:18-20)
         Entry e{};
         memset(&e, 0, sizeof e);
         e.first_prim = (uint32_t)prims.size();
@@ -544,6 +540,7 @@ int pt::scene_build(pt_scene* s) {
         default:
             return set_error("pt_world_build: unsupported object kind");
         }
+        e.n_prims = (uint32_t)prims.size() - e.first_prim;
         Box world = inst >= 0 ? xform_box(local, insts[inst]) : local;
         tlas_items.push_back(BuildItem{world, world.centroid(), (uint32_t)entries.size()});
         entries.push_back(e);

@@ -49,7 +49,8 @@ struct Entry {           // one per world-level object (lights list first, then 
     int32_t inst;
     uint32_t blas_root;  // node index (ENTRY_MESH)
     float extent;        // ENTRY_MESH: max |coordinate| of the mesh's (local-space) BVH boxes
-    uint32_t pad[3];
+    uint32_t n_prims;    // 1 (sphere, quad), 6 (cuboid) or the triangle count (mesh)
+    uint32_t pad[2];
 };
 struct SphereD { double r, p1[3], p2[3]; };
 struct QuadD { double q[3], u[3], v[3], w[3], n[3], d; };
