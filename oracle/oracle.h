@@ -48,6 +48,9 @@ int orc_mat_metal(orc_scene*, int color_tex, int rough_tex);
 int orc_mat_glass(orc_scene*, int color_tex, int rough_tex, double anisotropic, double ior);
 int orc_mat_principled(orc_scene*, int color_tex, const double params[11]);
 int orc_mat_light(orc_scene*, int emission_tex);
+int orc_mat_mix(orc_scene*, double t, int mat1, int mat2);          /* mix.rs */
+int orc_mat_sheen(orc_scene*, double r, double g, double b, double sheen_tint);   /* sheen.rs */
+int orc_mat_clearcoat(orc_scene*, double clearcoat_gloss);            /* clearcoat.rs */
 /* geometry (hittable/) */
 int orc_sphere(orc_scene*, double radius, const double p1[3], const double p2[3], int mat);
 int orc_quad(orc_scene*, const double q[3], const double u[3], const double v[3], int mat);
@@ -103,6 +106,8 @@ double orc_detmath(int which, double a, double b);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);
 double orc_probe(int which, const double* args);
+/* pdf (out4[0]) and eval (out4[1..3]) of one material at a synthetic hit with normal n, uv (0.5,0.5) */
+int orc_mat_probe(orc_scene*, int mat, const double* n, const double* wo, const double* wi, double* out4);
 /* primitive-level probe: closest hit of one ray against the built world.
  * out = {hit(0/1), t, prim_id, u, v, front_face, px,py,pz, gnx,gny,gnz, snx,sny,snz} */
 int orc_intersect(orc_scene*, const double origin[3], const double dir[3], double time, double out[15]);

@@ -132,6 +132,45 @@ extern "C" int orc_mat_principled(orc_scene* s, int color_tex, const double p[11
     s->mats.push_back(m);
     return (int)s->mats.size() - 1;
 }
+extern "C" int orc_mat_mix(orc_scene* s, double t, int m1, int m2) {
+    CHECK_MAT(s, m1);
+    CHECK_MAT(s, m2);
+    if (dynamic_cast<MixBxDf*>(s->mats[m1].get()) || dynamic_cast<MixBxDf*>(s->mats[m2].get())) return fail("nested mix materials are not supported");
+    auto m = std::make_shared<MixBxDf>();
+    m->t = clampd(t, 0.0, 1.0);   // mix.rs:16
+    m->a = s->mats[m1];
+    m->b = s->mats[m2];
+    s->mats.push_back(m);
+    return (int)s->mats.size() - 1;
+}
+extern "C" int orc_mat_sheen(orc_scene* s, double r, double g, double b, double sheen_tint) {
+    auto m = std::make_shared<SheenBRDF>();
+    m->base_color = V3{r, g, b};
+    m->sheen_tint = sheen_tint;
+    s->mats.push_back(m);
+    return (int)s->mats.size() - 1;
+}
+extern "C" int orc_mat_clearcoat(orc_scene* s, double clearcoat_gloss) {
+    auto m = std::make_shared<ClearcoatBRDF>();
+    m->alpha_g = (1.0 - clearcoat_gloss) * 0.1 + clearcoat_gloss * 0.001;   // clearcoat.rs:16
+    s->mats.push_back(m);
+    return (int)s->mats.size() - 1;
+}
+// material-level probe for the known-answer tests: pdf and eval of material `mat` at a hit with unit
+// normal n (geometric == shading), uv = (0.5, 0.5), for world-space view / light directions.
+extern "C" int orc_mat_probe(orc_scene* s, int mat, const double* n, const double* wo, const double* wi, double* out4) {
+    if (mat < 0 || mat >= (int)s->mats.size()) return -1;
+    HitInfo info{};
+    info.geometric_normal = info.shading_normal = normalize(V3{n[0], n[1], n[2]});
+    info.front_face = true;
+    info.u = info.v = 0.5;
+    info.mat = s->mats[mat].get();
+    V3 v{wo[0], wo[1], wo[2]}, l{wi[0], wi[1], wi[2]};
+    out4[0] = info.mat->pdf(v, l, info);
+    V3 f = info.mat->eval(v, l, info);
+    out4[1] = f.x; out4[2] = f.y; out4[3] = f.z;
+    return 0;
+}
 extern "C" int orc_mat_light(orc_scene* s, int tex) {
     CHECK_TEX_RGB(s, tex);
     auto m = std::make_shared<DiffuseLight>();

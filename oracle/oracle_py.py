@@ -60,6 +60,9 @@ def _load():
     lib.orc_mat_glass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
     lib.orc_mat_principled.argtypes = [C.c_void_p, C.c_int, d3]
     lib.orc_mat_light.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_mat_mix.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+    lib.orc_mat_sheen.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+    lib.orc_mat_clearcoat.argtypes = [C.c_void_p, C.c_double]
     lib.orc_sphere.argtypes = [C.c_void_p, C.c_double, d3, d3, C.c_int]
     lib.orc_quad.argtypes = [C.c_void_p, d3, d3, d3, C.c_int]
     lib.orc_cuboid.argtypes = [C.c_void_p, d3, d3, C.c_int]
@@ -82,6 +85,7 @@ def _load():
     lib.orc_philox4x32_10.restype = None
     lib.orc_rng_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.orc_rng_uniform.restype = C.c_double
+    lib.orc_mat_probe.argtypes = [C.c_void_p, C.c_int, d3, d3, d3, d3]
     lib.orc_probe.argtypes = [C.c_int, d3]
     lib.orc_probe.restype = C.c_double
     lib.orc_intersect.argtypes = [C.c_void_p, d3, d3, C.c_double, d3]
@@ -160,6 +164,13 @@ class Scene:
     def mat_glass(self, color_tex, rough_tex, aniso, ior): return _check(lib.orc_mat_glass(self.handle, color_tex, rough_tex, aniso, ior))
     def mat_principled(self, color_tex, params): return _check(lib.orc_mat_principled(self.handle, color_tex, (C.c_double * 11)(*params)))
     def mat_light(self, tex): return _check(lib.orc_mat_light(self.handle, tex))
+    def mat_mix(self, t, m1, m2): return _check(lib.orc_mat_mix(self.handle, t, m1, m2))
+    def mat_sheen(self, rgb, sheen_tint): return _check(lib.orc_mat_sheen(self.handle, rgb[0], rgb[1], rgb[2], sheen_tint))
+    def mat_clearcoat(self, gloss): return _check(lib.orc_mat_clearcoat(self.handle, gloss))
+    def mat_probe(self, mat, n, wo, wi):
+        out = (C.c_double * 4)()
+        _check(lib.orc_mat_probe(self.handle, mat, _d3(n), _d3(wo), _d3(wi), out))
+        return out[0], np.array(out[1:4])
     def sphere(self, r, p1, p2, mat): return _check(lib.orc_sphere(self.handle, r, _d3(p1), _d3(p2), mat))
     def quad(self, q, u, v, mat): return _check(lib.orc_quad(self.handle, _d3(q), _d3(u), _d3(v), mat))
     def cuboid(self, a, b, mat): return _check(lib.orc_cuboid(self.handle, _d3(a), _d3(b), mat))

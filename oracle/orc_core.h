@@ -490,6 +490,72 @@ struct PrincipledBSDF : Material {  // principled.rs (uses geometric_normal ever
     }
 };
 
+struct MixBxDf : Material {  // mix.rs (never instantiated by the reference's scenes; part of bsdf/)
+    double t;
+    std::shared_ptr<Material> a, b;
+    bool sample(const Ray& ray, const HitInfo& info, Rng& rng, V3& out) const override {
+        double p = rng.gen();
+        return t < p ? a->sample(ray, info, rng, out) : b->sample(ray, info, rng, out);
+    }
+    double pdf(V3 v, V3 l, const HitInfo& info) const override {
+        double p1 = (1.0 - t) * a->pdf(v, l, info);
+        double p2 = t * b->pdf(v, l, info);
+        return p1 + p2;
+    }
+    V3 eval(V3 v, V3 l, const HitInfo& info) const override {
+        V3 w1 = (1.0 - t) * a->eval(v, l, info);
+        V3 w2 = t * b->eval(v, l, info);
+        return w1 + w2;
+    }
+};
+struct SheenBRDF : Material {  // sheen.rs (geometric normal, colour is a plain Vec3)
+    V3 base_color;
+    double sheen_tint;
+    bool sample(const Ray&, const HitInfo& info, Rng& rng, V3& out) const override {
+        out = to_world(info.geometric_normal, cosine_sample_hemisphere(rng));
+        return true;
+    }
+    double pdf(V3, V3 light_dir, const HitInfo& info) const override {
+        V3 l = to_local(info.geometric_normal, light_dir);
+        return std::fabs(l.z) / PI;
+    }
+    V3 eval(V3 view_dir, V3 light_dir, const HitInfo& info) const override {
+        V3 v = to_local(info.geometric_normal, view_dir);
+        V3 l = to_local(info.geometric_normal, light_dir);
+        V3 h = normalize(v + l);
+        V3 c_sheen = vlerp(splat(1.0), tint(base_color), sheen_tint);
+        return c_sheen * powi5(1.0 - std::fabs(dot(l, h))) * std::fabs(l.z);
+    }
+};
+struct ClearcoatBRDF : Material {  // clearcoat.rs (shading normal)
+    double alpha_g;
+    bool sample(const Ray& ray, const HitInfo& info, Rng& rng, V3& out) const override {
+        V3 v = to_local(info.shading_normal, -ray.d);
+        V3 h = gtr1::sample_microfacet_normal(0.25, rng);
+        V3 dir = to_world(info.shading_normal, reflect(-v, h));
+        if (dot(dir, info.shading_normal) <= 0.0) return false;
+        out = dir;
+        return true;
+    }
+    double pdf(V3 view_dir, V3 light_dir, const HitInfo& info) const override {
+        V3 v = to_local(info.shading_normal, view_dir);
+        V3 l = to_local(info.shading_normal, light_dir);
+        V3 h = normalize(v + l);
+        double pdf_h = ggx::G1(v, 0.25) * std::fabs(dot(v, h)) * gtr1::D(std::fabs(dot(l, h)), alpha_g) / std::fabs(v.z);
+        double jacobian = 1.0 / (4.0 * std::fabs(dot(l, h)));
+        return pdf_h * jacobian;
+    }
+    V3 eval(V3 view_dir, V3 light_dir, const HitInfo& info) const override {
+        V3 v = to_local(info.shading_normal, view_dir);
+        V3 l = to_local(info.shading_normal, light_dir);
+        V3 h = normalize(v + l);
+        double d = gtr1::D(std::fabs(dot(l, h)), alpha_g);
+        double g = ggx::G(v, l, 0.25);
+        V3 f = fresnel_schlick(splat(r0_of(1.5)), dot(l, h));
+        return std::fabs(l.z) * (f * d * g / (4.0 * std::fabs(l.z) * std::fabs(v.z)));
+    }
+};
+
 struct DiffuseLight : Material {  // material.rs:150-191 (Q5)
     std::shared_ptr<TexRGB> emission;
     bool sample(const Ray&, const HitInfo&, Rng&, V3&) const override { return false; }

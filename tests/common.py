@@ -94,8 +94,14 @@ def random_scene(seed, with_mesh=True, with_lights=True, n_objects=10, sphere_li
     U = lambda lo, hi: float(rng.uniform(lo, hi))
     col = lambda: (U(0.05, 0.95), U(0.05, 0.95), U(0.05, 0.95))
 
-    def material():
-        k = int(rng.integers(0, 4))
+    def material(allow_mix=True):
+        k = int(rng.integers(0, 7 if allow_mix else 6))
+        if k == 4:
+            return s.add("mat_sheen", col(), U(0, 1))
+        if k == 5:
+            return s.add("mat_clearcoat", U(0, 1))
+        if k == 6:
+            return s.add("mat_mix", U(-0.2, 1.2), material(False), material(False))
         tex = s.add("tex_solid_rgb", *col())
         if rng.random() < 0.25:
             tex = s.add("tex_checker", U(0.2, 1.5), tex, s.add("tex_solid_rgb", *col()))

@@ -263,6 +263,46 @@ def test_mesh_with_normals_uvs_image_textures_and_normal_map(pt, det, ctx):
     gs.close(); os_.close()
 
 
+def test_sheen_clearcoat_mix_bit_exact(pt, det, ctx):
+    """The three bsdf/ materials no scene script instantiates (sheen.rs, clearcoat.rs, mix.rs), under a quad
+    light (NEE + MIS exercise pdf and eval) and on an instanced normal-carrying mesh (shading != geometric
+    normal separates sheen's geometric frame from clearcoat's shading frame)."""
+    spec = SceneSpec()
+    rgb = lambda r, g, b: spec.add("tex_solid_rgb", r, g, b)
+    sheen = spec.add("mat_sheen", (0.8, 0.3, 0.1), 0.6)
+    coat = spec.add("mat_clearcoat", 0.7)
+    diffuse = spec.add("mat_diffuse", rgb(0.6, 0.6, 0.7), -1)
+    prin = spec.add("mat_principled", rgb(0.9, 0.5, 0.2), [0.3, 0.1, 0.6, 0.4, 0.5, 0.2, 0.3, 0.5, 0.8, 0.6, 1.45])
+    glass = spec.add("mat_glass", rgb(1.0, 1.0, 1.0), spec.add("tex_solid_f", 0.1), 0.0, 1.5)
+    mixes = [spec.add("mat_mix", 0.3, diffuse, coat), spec.add("mat_mix", 0.5, prin, sheen),
+             spec.add("mat_mix", 0.0, sheen, glass), spec.add("mat_mix", 1.0, coat, glass), spec.add("mat_mix", 0.8, sheen, coat)]
+    spec.add("world_add_object", spec.add("quad", (-6.0, 0.0, -6.0), (0.0, 0.0, 12.0), (12.0, 0.0, 0.0), mixes[0]))
+    mats = [sheen, coat] + mixes
+    for i, m in enumerate(mats):
+        x = -3.0 + i
+        spec.add("world_add_object", spec.add("sphere", 0.45, (x, 0.45, 0.0), (x, 0.45, 0.0), m))
+    P, I = icosphere(1)
+    N = (P / np.linalg.norm(P, axis=1, keepdims=True)).astype(np.float32)
+    mesh = spec.add("mesh", 0.8, P, I, N, None, mixes[4])
+    spec.add("world_add_object", spec.add("instance", mesh, (0.0, 1.0, 0.0), 0.5, (0.0, 1.9, -0.5)))
+    spec.add("world_add_light", spec.add("quad", (-1.5, 4.0, -1.5), (3.0, 0.0, 0.0), (0.0, 0.0, 3.0),
+                                         spec.add("mat_light", rgb(7.0, 7.0, 6.0))))
+    spec.add("world_build")
+    spec.camera = default_camera(look_from=(0.0, 2.5, 7.0), look_at=(0.0, 0.8, 0.0), vfov=45.0)
+    gs, os_ = pt.Scene(ctx), det.Scene()
+    gres, ores = spec.replay(gs), spec.replay(os_)
+    gcam, ocam = spec.make_camera(pt.Camera, gres), spec.make_camera(det.Camera, ores)
+    ga, st = gs.render(gcam, 5, 0, 8, slots_per_pixel=1)
+    oa, cnt = os_.render(ocam, 5, 0, 8)
+    assert st.segments == cnt["segments"]
+    np.testing.assert_array_equal(ga, oa)
+    assert np.isfinite(ga).mean() > 0.99 and ga[np.isfinite(ga)].max() > 0
+    gd, _ = gs.render(gcam, 5, 0, 8)            # dynamic slot assignment + class sort: same sums up to f64 add order
+    fin = np.isfinite(oa) & np.isfinite(gd)
+    np.testing.assert_allclose(gd[fin], oa[fin], rtol=1e-11, atol=1e-11)
+    gs.close(); os_.close()
+
+
 # ---- edge cases ------------------------------------------------------------------------------------
 def test_edge_cases(pt, det, ctx):
     gs, os_ = pt.Scene(ctx), det.Scene()
@@ -297,6 +337,10 @@ def test_error_behaviour(pt, ctx):
     with pytest.raises(pt.PtError, match="empty"):
         s.world_build()
     m = s.mat_diffuse(s.tex_solid_rgb(1, 1, 1))
+    with pytest.raises(pt.PtError, match="bad material"):
+        s.mat_mix(0.5, m, 17)
+    with pytest.raises(pt.PtError, match="nested"):
+        s.mat_mix(0.5, s.mat_mix(0.5, m, s.mat_clearcoat(0.5)), m)
     q = s.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
     s.world_add_object(q)
     with pytest.raises(pt.PtError, match="already placed"):

@@ -10,6 +10,7 @@ parity stays "unpinned".
 """
 import os
 
+import math
 import numpy as np
 import pytest
 
@@ -46,6 +47,41 @@ def test_kat_principled_lobes(orc):   # a24: principled.rs:79-100
     cornell = [orc.probe(4, 0.01, 0.91, 0.91, float(i)) for i in range(4)]
     assert cornell == pytest.approx([0.0677, 0.0753, 0.6843, 0.1728], abs=5e-5)
     assert sum(bunny) == pytest.approx(1.0, rel=1e-15)
+
+
+def test_kat_sheen_clearcoat_mix(orc):   # sheen.rs:32-44, clearcoat.rs:37-60, mix.rs:34-44
+    """pdf/eval of the three bsdf/ materials no scene script uses, against a closed-form numpy restatement
+    (normal = +z so that only rotation-invariant quantities of the local frame enter)."""
+    s = orc.Scene()
+    base, tint_w, gloss, t = np.array([0.8, 0.3, 0.1]), 0.6, 0.7, 0.35
+    sheen, coat = s.mat_sheen(base, tint_w), s.mat_clearcoat(gloss)
+    mix = s.mat_mix(t, sheen, coat)
+    n = (0.0, 0.0, 1.0)
+    v = np.array([0.3, -0.2, 0.8]); v /= np.linalg.norm(v)
+    l = np.array([-0.5, 0.1, 0.6]); l /= np.linalg.norm(l)
+    h = (v + l) / np.linalg.norm(v + l)
+    lum = base @ np.array([0.2126, 0.7152, 0.0722])
+    c_sheen = (1 - tint_w) + tint_w * base / lum
+    f_sheen = c_sheen * (1 - abs(l @ h)) ** 5 * abs(l[2])
+    p_sheen = abs(l[2]) / math.pi
+    ag = (1 - gloss) * 0.1 + gloss * 0.001
+    a2 = ag * ag
+    lh = abs(l @ h)
+    d = (a2 - 1) / (math.pi * (1 + (a2 - 1) * lh * lh) * math.log2(a2))
+    g1 = lambda w: 2 * abs(w[2]) / (abs(w[2]) + math.sqrt(w[2] * w[2] * (1 - 0.0625) + 0.0625))
+    p_coat = g1(v) * abs(v @ h) * d / abs(v[2]) / (4 * lh)
+    f_coat = (0.04 + 0.96 * (1 - l @ h) ** 5) * d * g1(v) * g1(l) / (4 * abs(v[2])) * np.ones(3)
+    ps, fs = s.mat_probe(sheen, n, v, l)
+    pc, fc = s.mat_probe(coat, n, v, l)
+    pm, fm = s.mat_probe(mix, n, v, l)
+    assert ps == pytest.approx(p_sheen, rel=1e-14) and fs == pytest.approx(f_sheen, rel=1e-13)
+    assert pc == pytest.approx(p_coat, rel=1e-13) and fc == pytest.approx(f_coat, rel=1e-13)
+    assert pm == (1 - t) * ps + t * pc and np.array_equal(fm, (1 - t) * fs + t * fc)
+    # MixBxDf::new clamps t (mix.rs:16); nested mixes are rejected by this build
+    assert s.mat_probe(s.mat_mix(1.7, sheen, coat), n, v, l)[0] == 0.0 * ps + 1.0 * pc
+    with pytest.raises(Exception):
+        s.mat_mix(0.5, mix, coat)
+    s.close()
 
 
 def test_kat_camera_init(orc):   # a2: camera.rs:51-77

@@ -87,7 +87,7 @@ ABI_SYMBOLS = [
     "pt_last_error", "pt_set_error_message", "pt_ctx_create", "pt_ctx_destroy", "pt_device_name",
     "pt_scene_create", "pt_scene_destroy", "pt_scene_ctx",
     "pt_tex_solid_rgb", "pt_tex_solid_f", "pt_tex_checker", "pt_tex_image_rgb8",
-    "pt_mat_diffuse", "pt_mat_metal", "pt_mat_glass", "pt_mat_principled", "pt_mat_light",
+    "pt_mat_diffuse", "pt_mat_metal", "pt_mat_glass", "pt_mat_principled", "pt_mat_light", "pt_mat_mix", "pt_mat_sheen", "pt_mat_clearcoat",
     "pt_sphere", "pt_quad", "pt_cuboid", "pt_mesh", "pt_instance",
     "pt_world_add_object", "pt_world_add_light", "pt_world_build", "pt_world_prim_count",
     "pt_load_obj", "pt_load_hdr_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
@@ -122,6 +122,9 @@ def _load():
     lib.pt_mat_glass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
     lib.pt_mat_principled.argtypes = [C.c_void_p, C.c_int, d3]
     lib.pt_mat_light.argtypes = [C.c_void_p, C.c_int]
+    lib.pt_mat_mix.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+    lib.pt_mat_sheen.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+    lib.pt_mat_clearcoat.argtypes = [C.c_void_p, C.c_double]
     lib.pt_sphere.argtypes = [C.c_void_p, C.c_double, d3, d3, C.c_int]
     lib.pt_quad.argtypes = [C.c_void_p, d3, d3, d3, C.c_int]
     lib.pt_cuboid.argtypes = [C.c_void_p, d3, d3, C.c_int]
@@ -240,6 +243,9 @@ class Scene:
         return _check(lib.pt_mat_principled(self.handle, color_tex, (C.c_double * 11)(*params)), "mat_principled")
 
     def mat_light(self, tex): return _check(lib.pt_mat_light(self.handle, tex), "mat_light")
+    def mat_mix(self, t, m1, m2): return _check(lib.pt_mat_mix(self.handle, t, m1, m2), "mat_mix")
+    def mat_sheen(self, rgb, sheen_tint): return _check(lib.pt_mat_sheen(self.handle, rgb[0], rgb[1], rgb[2], sheen_tint), "mat_sheen")
+    def mat_clearcoat(self, gloss): return _check(lib.pt_mat_clearcoat(self.handle, gloss), "mat_clearcoat")
     def sphere(self, r, p1, p2, mat): return _check(lib.pt_sphere(self.handle, r, _d3(p1), _d3(p2), mat), "sphere")
     def quad(self, q, u, v, mat): return _check(lib.pt_quad(self.handle, _d3(q), _d3(u), _d3(v), mat), "quad")
     def cuboid(self, a, b, mat): return _check(lib.pt_cuboid(self.handle, _d3(a), _d3(b), mat), "cuboid")

@@ -176,7 +176,13 @@ PT_DEV V3 sample_dielectric(V3 v, V3 h, double eta_i, double eta_o, Rng& rng) { 
 
 // ---- BxDFMaterial::sample (bsdf/mod.rs:23) ----------------------------------------------
 // wo = -ray.direction. Returns false where the reference returns None.
-PT_DEV bool mat_sample(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, Rng& rng, double two_pi_scale, V3& dir) {
+PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, Rng& rng, double two_pi_scale, V3& dir) {
+    const MatD* leaf = &mat;
+    if (mat.kind == MAT_MIX) {   // mix.rs:25-32: the selector is drawn first, then the chosen child samples
+        double p = rng_f64(rng);
+        leaf = &sc.mats[mat.p[0] < p ? mat.color_tex : mat.rough_tex];
+    }
+    const MatD& m = *leaf;
     switch (m.kind) {
     case MAT_DIFFUSE: {   // diffuse.rs:51-54
         Frame f = frame_to_z(h.sn);
@@ -231,13 +237,27 @@ PT_DEV bool mat_sample(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, Rn
         dir = d;
         return true;
     }
+    case MAT_SHEEN: {     // sheen.rs:27-30
+        Frame f = frame_to_z(h.gn);
+        dir = to_world(f, cosine_sample_hemisphere(rng, two_pi_scale));
+        return true;
+    }
+    case MAT_CLEARCOAT: { // clearcoat.rs:23-35
+        Frame f = frame_to_z(h.sn);
+        V3 v = to_local(f, wo);
+        V3 hv = gtr1_sample_microfacet_normal(0.25, rng);
+        V3 d = to_world(f, reflect(-v, hv));
+        if (dot(d, h.sn) <= 0.0) return false;
+        dir = d;
+        return true;
+    }
     default:   // MAT_LIGHT: material.rs:168-170
         return false;
     }
 }
 
 // ---- BxDFMaterial::pdf + eval (cosine included in eval) -----------------------------------
-PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, double& pdf, V3& brdf) {
+PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, double& pdf, V3& brdf) {
     switch (m.kind) {
     case MAT_DIFFUSE: {   // diffuse.rs:56-65
         Frame f = frame_to_z(h.sn);
@@ -333,10 +353,58 @@ PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, 
         brdf = acc * fabs(l.z);
         return;
     }
+    case MAT_SHEEN: {     // sheen.rs:32-44
+        Frame f = frame_to_z(h.gn);
+        V3 v = to_local(f, wo), l = to_local(f, wi);
+        V3 hv = normalize(v + l);
+        V3 c_sheen = vlerp(splat(1.0), tint(V3{m.p[0], m.p[1], m.p[2]}), m.p[3]);
+        pdf = fabs(l.z) / D_PI;
+        brdf = c_sheen * powi5(1.0 - fabs(dot(l, hv))) * fabs(l.z);
+        return;
+    }
+    case MAT_CLEARCOAT: { // clearcoat.rs:37-60
+        Frame f = frame_to_z(h.sn);
+        V3 v = to_local(f, wo), l = to_local(f, wi);
+        V3 hv = normalize(v + l);
+        double l_h = fabs(dot(l, hv));
+        double dc = gtr1_D(l_h, m.alpha_g);
+        double g1v = ggx_G1(v, 0.25);
+        double pdf_h = g1v * fabs(dot(v, hv)) * dc / fabs(v.z);
+        pdf = pdf_h * (1.0 / (4.0 * l_h));
+        double gc = g1v * ggx_G1(l, 0.25);
+        V3 fc = fresnel_schlick(splat(r0_of(1.5)), dot(l, hv));
+        brdf = fabs(l.z) * (fc * dc * gc / (4.0 * fabs(l.z) * fabs(v.z)));
+        return;
+    }
     default:   // MAT_LIGHT: material.rs:172-178
         pdf = 1.0;
         brdf = V3{1.0, 1.0, 1.0};
         return;
+    }
+}
+// BxDFMaterial::pdf + eval incl. MixBxDf (mix.rs:34-44): (1-t)*child1 + t*child2. One non-unrolled loop
+// so that the leaf code above is instantiated once.
+PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, double& pdf, V3& brdf) {
+    const bool mix = m.kind == MAT_MIX;
+    const int n = mix ? 2 : 1;
+    pdf = 0.0;
+    brdf = V3{0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int c = 0; c < n; ++c) {
+        const MatD& lm = mix ? sc.mats[c == 0 ? m.color_tex : m.rough_tex] : m;
+        double pc;
+        V3 fc;
+        leaf_pdf_eval(sc, lm, h, wo, wi, pc, fc);
+        if (!mix) {
+            pdf = pc;
+            brdf = fc;
+        } else {
+            const double w = c == 0 ? 1.0 - m.p[0] : m.p[0];
+            const double wp = w * pc;
+            const V3 wf = w * fc;
+            pdf = c == 0 ? wp : pdf + wp;
+            brdf = c == 0 ? wf : brdf + wf;
+        }
     }
 }
 

@@ -655,8 +655,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             shade_slot(sc, cam, pool, cnt, seed, base + threadIdx.x, lane, n_done, n_died);
     } else {
         __shared__ uint16_t s_perm[SORT_WINDOW];
-        __shared__ uint32_t s_cnt[8][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
-        __shared__ uint32_t s_hist[8], s_next;
+        constexpr uint32_t NCLASS = 3u + MAT_KINDS, K_IDLE = 1u + MAT_KINDS, K_DEAD = 2u + MAT_KINDS;   // miss, one per material kind, idle, dead
+        __shared__ uint32_t s_cnt[NCLASS][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
+        __shared__ uint32_t s_hist[NCLASS], s_next;
         constexpr int PER = SORT_WINDOW / BLOCK, NGRP = SORT_WINDOW / 64;
         const int wave = (int)(threadIdx.x >> 6);
         for (uint32_t wbase = blockIdx.x * SORT_WINDOW; wbase < pool.n_alloc; wbase += gridDim.x * SORT_WINDOW) {
@@ -671,8 +672,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 const uint32_t s0 = wbase + (uint32_t)j * BLOCK + threadIdx.x;
                 const uint32_t b0 = pool.bounce[s0];
                 uint32_t key;
-                if (b0 == SLOT_DEAD) key = 7u;
-                else if (b0 == SLOT_IDLE) key = 6u;
+                if (b0 == SLOT_DEAD) key = K_DEAD;
+                else if (b0 == SLOT_IDLE) key = K_IDLE;
                 else {
                     const uint32_t g0 = pool.hit_prim[s0];
                     key = g0 == HIT_NONE ? 0u : 1u + sc.mats[sc.prims[g0].mat].kind;
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 keys |= key << (4 * j);
                 rank[j] = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 8u; ++k) {
+                for (uint32_t k = 0; k < NCLASS; ++k) {
                     const unsigned long long m = __ballot(key == k);
                     if (key == k) rank[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (lane == 0) s_cnt[k][j * (BLOCK / 64) + wave] = (uint32_t)__popcll(m);
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             }
             (void)ranks;
             __syncthreads();
-            if (threadIdx.x < 8) {   // one thread per class: exclusive prefix over the groups in slot order
+            if (threadIdx.x < NCLASS) {   // one thread per class: exclusive prefix over the groups in slot order
                 uint32_t acc = 0;
                 for (int g = 0; g < NGRP; ++g) {
                     const uint32_t c = s_cnt[threadIdx.x][g];
@@ -698,23 +699,23 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 s_hist[threadIdx.x] = acc;
             }
             __syncthreads();
-            uint32_t class_base[8];
+            uint32_t class_base[NCLASS];
             {
                 uint32_t acc = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { class_base[k] = acc; acc += s_hist[k]; }
+                for (uint32_t k = 0; k < NCLASS; ++k) { class_base[k] = acc; acc += s_hist[k]; }
             }
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 const uint32_t key = (keys >> (4 * j)) & 15u;
                 uint32_t cb = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) cb = key == (uint32_t)k ? class_base[k] : cb;
+                for (uint32_t k = 0; k < NCLASS; ++k) cb = key == k ? class_base[k] : cb;
                 const uint32_t pos = cb + s_cnt[key][j * (BLOCK / 64) + wave] + rank[j];
                 s_perm[pos] = (uint16_t)(j * BLOCK + threadIdx.x);
             }
             __syncthreads();
-            const uint32_t n_live = SORT_WINDOW - s_hist[7];
+            const uint32_t n_live = SORT_WINDOW - s_hist[K_DEAD];
             for (;;) {
                 uint32_t g = 0;
                 if (lane == 0) g = atomicAdd(&s_next, 1u);

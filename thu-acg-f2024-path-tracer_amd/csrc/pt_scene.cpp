@@ -142,6 +142,25 @@ extern "C" int pt_mat_principled(pt_scene* s, int color_tex, const double p[11])
     m.alpha_g = (1.0 - gloss) * 0.1 + gloss * 0.001;       // :75-77
     return push_mat(s, m);
 }
+extern "C" int pt_mat_mix(pt_scene* s, double t, int m1, int m2) {   // MixBxDf::new mix.rs:14-20
+    if (!MAT_OK(s, m1) || !MAT_OK(s, m2)) return set_error("pt_mat_mix: bad material handle");
+    if (s->mats[m1].kind == MAT_MIX || s->mats[m2].kind == MAT_MIX) return set_error("pt_mat_mix: nested mix materials are not supported");
+    MatD m = blank_mat(MAT_MIX);
+    m.p[0] = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);   // t.clamp(0, 1)
+    m.color_tex = m1;
+    m.rough_tex = m2;
+    return push_mat(s, m);
+}
+extern "C" int pt_mat_sheen(pt_scene* s, double r, double g, double b, double sheen_tint) {   // SheenBRDF::new sheen.rs:17-22
+    MatD m = blank_mat(MAT_SHEEN);
+    m.p[0] = r; m.p[1] = g; m.p[2] = b; m.p[3] = sheen_tint;
+    return push_mat(s, m);
+}
+extern "C" int pt_mat_clearcoat(pt_scene* s, double clearcoat_gloss) {   // ClearcoatBRDF::new clearcoat.rs:14-18
+    MatD m = blank_mat(MAT_CLEARCOAT);
+    m.alpha_g = (1.0 - clearcoat_gloss) * 0.1 + clearcoat_gloss * 0.001;
+    return push_mat(s, m);
+}
 extern "C" int pt_mat_light(pt_scene* s, int tex) {
     if (!TEX_RGB_OK(s, tex)) return set_error("pt_mat_light: bad emission texture");
     MatD m = blank_mat(MAT_LIGHT);

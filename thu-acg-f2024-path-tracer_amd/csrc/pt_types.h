@@ -66,7 +66,10 @@ struct TexD {
     double v[3];
     double inv_scale;
 };
-enum MatKind : uint32_t { MAT_DIFFUSE = 0, MAT_METAL = 1, MAT_GLASS = 2, MAT_PRINCIPLED = 3, MAT_LIGHT = 4 };
+enum MatKind : uint32_t { MAT_DIFFUSE = 0, MAT_METAL = 1, MAT_GLASS = 2, MAT_PRINCIPLED = 3, MAT_LIGHT = 4,
+                          MAT_SHEEN = 5, MAT_CLEARCOAT = 6, MAT_MIX = 7, MAT_KINDS = 8 };
+// MAT_SHEEN: p[0..2] = base colour, p[3] = sheen_tint (sheen.rs). MAT_CLEARCOAT: alpha_g (clearcoat.rs).
+// MAT_MIX: p[0] = t, color_tex / rough_tex hold the two child MATERIAL indices (mix.rs; children are leaves).
 struct MatD {
     uint32_t kind;
     int32_t color_tex, rough_tex, nmap_tex;

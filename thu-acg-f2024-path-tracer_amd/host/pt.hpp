@@ -192,6 +192,42 @@ struct DiffuseLight : BxDFMaterial {   // material.rs:155-164
     }
 };
 
+struct MixBxDf : BxDFMaterial {   // mix.rs:14-20
+    double t;
+    MatPtr bxdf1, bxdf2;
+    static std::shared_ptr<MixBxDf> new_(double t, MatPtr a, MatPtr b) { auto m = std::make_shared<MixBxDf>(); m->t = t; m->bxdf1 = a; m->bxdf2 = b; return m; }
+    int emit(Emitter& e) const override {
+        auto it = e.done.find(this);
+        if (it != e.done.end()) return it->second;
+        int h = pt_mat_mix(e.scene, t, bxdf1->emit(e), bxdf2->emit(e));
+        if (h < 0) panic("MixBxDf");
+        return e.done[this] = h;
+    }
+};
+struct SheenBRDF : BxDFMaterial {   // sheen.rs:17-22
+    Vec3 base_color;
+    double sheen_tint;
+    static std::shared_ptr<SheenBRDF> new_(Vec3 c, double tint) { auto m = std::make_shared<SheenBRDF>(); m->base_color = c; m->sheen_tint = tint; return m; }
+    int emit(Emitter& e) const override {
+        auto it = e.done.find(this);
+        if (it != e.done.end()) return it->second;
+        int h = pt_mat_sheen(e.scene, base_color.x, base_color.y, base_color.z, sheen_tint);
+        if (h < 0) panic("SheenBRDF");
+        return e.done[this] = h;
+    }
+};
+struct ClearcoatBRDF : BxDFMaterial {   // clearcoat.rs:14-18
+    double clearcoat_gloss;
+    static std::shared_ptr<ClearcoatBRDF> new_(double gloss) { auto m = std::make_shared<ClearcoatBRDF>(); m->clearcoat_gloss = gloss; return m; }
+    int emit(Emitter& e) const override {
+        auto it = e.done.find(this);
+        if (it != e.done.end()) return it->second;
+        int h = pt_mat_clearcoat(e.scene, clearcoat_gloss);
+        if (h < 0) panic("ClearcoatBRDF");
+        return e.done[this] = h;
+    }
+};
+
 // ---- hittables (src/hittable/*.rs) -------------------------------------------------------
 struct Hittable {
     virtual ~Hittable() = default;
