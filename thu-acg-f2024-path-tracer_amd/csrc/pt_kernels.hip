@@ -24,6 +24,36 @@ constexpr int BLOCK = 256;
 template <class T> PT_DEV T ldnt(const T* p) { return __builtin_nontemporal_load(p); }
 template <class T> PT_DEV void stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
+// ---- path records (pt_types.h RayRec / PathRec): one lane moves one whole 64-byte record --------
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+PT_DEV RayD load_ray(const PoolD& pool, uint32_t s) {
+    const d2v* p = reinterpret_cast<const d2v*>(&pool.ray[s]);
+    const d2v a = p[0], b = p[1], c = p[2], d = p[3];
+    return RayD{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, d.x};
+}
+PT_DEV void store_ray(const PoolD& pool, uint32_t s, const RayD& r) {
+    d2v* p = reinterpret_cast<d2v*>(&pool.ray[s]);
+    p[0] = d2v{r.o.x, r.o.y};
+    p[1] = d2v{r.o.z, r.d.x};
+    p[2] = d2v{r.d.y, r.d.z};
+    p[3] = d2v{r.time, 0.0};
+}
+struct PathS { V3 thr, rad; uint32_t sample, draw, pixel; };
+PT_DEV PathS load_path(const PoolD& pool, uint32_t s) {
+    const d2v* p = reinterpret_cast<const d2v*>(&pool.path[s]);
+    const d2v a = p[0], b = p[1], c = p[2];
+    const u4v u = *reinterpret_cast<const u4v*>(p + 3);
+    return PathS{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, u.x, u.y, u.z};
+}
+PT_DEV void store_path(const PoolD& pool, uint32_t s, const PathS& q) {
+    d2v* p = reinterpret_cast<d2v*>(&pool.path[s]);
+    p[0] = d2v{q.thr.x, q.thr.y};
+    p[1] = d2v{q.thr.z, q.rad.x};
+    p[2] = d2v{q.rad.y, q.rad.z};
+    *reinterpret_cast<u4v*>(p + 3) = u4v{q.sample, q.draw, q.pixel, 0u};
+}
+
 // ---------------------------------------------------------------------------------------
 // Closest-hit traversal. Two-level BVH2 walked with one per-lane stack held in LDS
 // (stack[level][lane]: a wave touches 64 consecutive dwords per level -> conflict free).
@@ -216,30 +246,26 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
             has_work = s < pool.n_slots && (unsigned long long)s < pool.total_work;
             idle = has_work && !work_to_pixel(pool, s, pixel, sample);
             if (!has_work || idle) { pixel = 0; sample = 0; }
-            pool.pixel[s] = pixel;
         } else {
             pixel = s % pool.n_pixels;
             sample = pool.spp_begin + s / pool.n_pixels;
             has_work = s < pool.n_slots && sample < pool.spp_end;
             pool.ax[s] = 0.0; pool.ay[s] = 0.0; pool.az[s] = 0.0;
         }
-        pool.rx[s] = 0.0; pool.ry[s] = 0.0; pool.rz[s] = 0.0;
-        pool.tx[s] = 1.0; pool.ty[s] = 1.0; pool.tz[s] = 1.0;
-        pool.sample[s] = sample;
         pool.hit_prim[s] = HIT_NONE;
-        pool.hit_t[s] = D_INF;
+        PathS q{V3{1.0, 1.0, 1.0}, V3{0.0, 0.0, 0.0}, sample, 0u, pixel};
         if (!has_work || idle) {
             pool.bounce[s] = idle ? SLOT_IDLE : SLOT_DEAD;
-            pool.draw[s] = 0;
+            store_path(pool, s, q);
+            store_ray(pool, s, RayD{});
             continue;
         }
         Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, 0u};
         RayD r = generate_ray(cam, pixel / cam.width, pixel % cam.width, rng);
-        pool.ox[s] = r.o.x; pool.oy[s] = r.o.y; pool.oz[s] = r.o.z;
-        pool.dx[s] = r.d.x; pool.dy[s] = r.d.y; pool.dz[s] = r.d.z;
-        pool.time[s] = r.time;
+        q.draw = rng.draw;
+        store_ray(pool, s, r);
+        store_path(pool, s, q);
         pool.bounce[s] = 0;
-        pool.draw[s] = rng.draw;
     }
 }
 
@@ -249,11 +275,11 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
 __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     unsigned long long nseg = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
         if (pool.bounce[s] >= SLOT_IDLE) continue;
-        RayD r{V3{ldnt(&pool.ox[s]), ldnt(&pool.oy[s]), ldnt(&pool.oz[s])}, V3{ldnt(&pool.dx[s]), ldnt(&pool.dy[s]), ldnt(&pool.dz[s])}, ldnt(&pool.time[s])};
+        RayD r = load_ray(pool, s);
         Closest c = closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
-        stnt(&pool.hit_t[s], c.t);
         stnt(&pool.hit_prim[s], (uint32_t)(c.id));
         ++nseg;
     }
@@ -273,9 +299,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 // dense waves whose lanes all do the same kind of work. The closest hit is order-independent
 // (minimum t, ties -> larger id), so the result is bit-identical to the batch kernel's.
 // ---------------------------------------------------------------------------------------
-// EXT_STACK = 24 entries keeps the block at 47 KB of LDS (3 blocks per CU); the host only selects this
-// kernel for scenes whose BVHs need <= 24 (pt_scene::stack_need), deeper scenes use the batch kernel.
-constexpr int EXT_WINDOW = 1024, EXT_STACK = 24, EXT_MAXI = 4;
+// The phase-A best hit of a ray waits in LDS (t and id), and the window's final primitive ids leave
+// with ONE coalesced store per slot: k_shade re-intersects the primitive (reconstruct_hit) and never
+// needs t, so 4 B per slot is all this kernel writes.
+// LDS per block: STACK x 1 KB (traversal stacks) + 19 KB; STACK = 20 gives 39 KB = 4 blocks per CU,
+// STACK = 24 gives 43 KB = 3 blocks per CU. The host picks the smallest STACK that covers the scene's
+// BVHs (pt_scene::stack_need); deeper scenes use the batch kernel.
+constexpr int EXT_WINDOW = 1024, EXT_MAXI = 4;
 
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
     RayD r = wray;
@@ -284,31 +314,36 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
     float t_max_f = t_max_f32(best.t);
     int sp = 0;
     uint32_t cur = e.blas_root;
+    // "while-while" traversal: every lane first descends until it HOLDS a triangle leaf (cheap f32 box
+    // tests; lanes that already found theirs idle), then the wave runs the expensive f64 triangle
+    // tests together. Interleaving the two per iteration made almost every iteration pay for a leaf.
     for (;;) {
-        if ((cur & REF_TYPE_MASK) == REF_NODE) {
+        while ((cur & REF_TYPE_MASK) == REF_NODE) {
             uint32_t c0, c1;
             const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
             if (n == 2 && sp < cap) stk[(sp++) * BLOCK] = c1;
-            if (n > 0) {
-                cur = c0;
-                continue;
-            }
-        } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
-            const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
-            for (uint32_t i = first; i < first + count; ++i) {
-                double t, u, v;
-                if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
-            }
-            t_max_f = t_max_f32(best.t);
+            if (n > 0) cur = c0;
+            else if (sp > 0) cur = stk[(--sp) * BLOCK];
+            else cur = REF_EMPTY;
         }
+        if ((cur & REF_TYPE_MASK) != REF_TRIS) break;             // REF_EMPTY: nothing left
+        const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
+        for (uint32_t i = first; i < first + count; ++i) {
+            double t, u, v;
+            if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
+        }
+        t_max_f = t_max_f32(best.t);
         if (sp == 0) break;
         cur = stk[(--sp) * BLOCK];
     }
 }
 
-__global__ __launch_bounds__(BLOCK, 4) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
-    __shared__ uint32_t stack[EXT_STACK * BLOCK];                 // 24 KB
-    __shared__ uint16_t s_items[EXT_WINDOW * EXT_MAXI];            //  8 KB  recorded mesh entries per ray
+template <int EXT_STACK, int MINB>
+__global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
+    __shared__ uint32_t stack[EXT_STACK * BLOCK];
+    __shared__ double s_best_t[EXT_WINDOW];                        //  8 KB  phase-A best hit of the rays with recorded meshes
+    __shared__ uint32_t s_best_id[EXT_WINDOW];                     //  4 KB  closest primitive of every slot of the window
+    __shared__ uint8_t s_items[EXT_WINDOW * EXT_MAXI];             //  4 KB  recorded mesh entries per ray
     __shared__ uint8_t s_nitems[EXT_WINDOW];
     __shared__ uint16_t s_rays[EXT_WINDOW];                        // rays with recorded meshes
     __shared__ uint32_t s_nrays, s_next;
@@ -317,17 +352,23 @@ __global__ __launch_bounds__(BLOCK, 4) void k_extend2(SceneD sc, PoolD pool, Cou
     const double t_min = 1e-3;                                     // camera.rs:171,179
     const float t_min_f = __double2float_rd(t_min);
     unsigned long long nseg = 0;
-    for (uint32_t wbase = blockIdx.x * EXT_WINDOW; wbase < pool.n_alloc; wbase += gridDim.x * EXT_WINDOW) {
-        if (threadIdx.x == 0) { s_nrays = 0; s_next = 0; }
+    __shared__ uint32_t s_win;
+    const uint32_t n_windows = pool.n_alloc / EXT_WINDOW;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
+    for (;;) {
+        if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_extend, 1ull); s_nrays = 0; s_next = 0; }
         __syncthreads();
+        if (s_win >= n_windows) break;
+        const uint32_t wbase = s_win * EXT_WINDOW;
         // ---- phase A: top-level tree only --------------------------------------------------------
         for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) {
             const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x, slot = wbase + sl;
             const bool alive = pool.bounce[slot] < SLOT_IDLE;
             uint32_t n_my = 0;
+            uint32_t id_a = HIT_NONE;
             if (alive) {
                 ++nseg;
-                const RayD r{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, ldnt(&pool.time[slot])};
+                const RayD r = load_ray(pool, slot);
                 const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
                 Closest best{D_INF, HIT_NONE};
                 float t_max_f = t_max_f32(best.t);
@@ -346,8 +387,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_extend2(SceneD sc, PoolD pool, Cou
                         const uint32_t ei = cur & 0x3FFFFFFFu;
                         const Entry e = sc.entries[ei];
                         if (e.kind == ENTRY_MESH) {
-                            if (n_my < (uint32_t)EXT_MAXI && ei < 0xFFFFu) {
-                                s_items[sl * EXT_MAXI + n_my++] = (uint16_t)ei;           // defer to phase B
+                            if (n_my < (uint32_t)EXT_MAXI && ei <= 0xFFu) {
+                                s_items[sl * EXT_MAXI + n_my++] = (uint8_t)ei;            // defer to phase B
                             } else {
                                 blas_pass(sc, r, e, t_min, t_min_f, stk + (size_t)sp * BLOCK, EXT_STACK - sp, best);   // overflow: walk it now
                                 t_max_f = t_max_f32(best.t);
@@ -365,15 +406,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_extend2(SceneD sc, PoolD pool, Cou
                     if (sp == 0) break;
                     cur = stk[(--sp) * BLOCK];
                 }
-                if (n_my == 0) {
-                    stnt(&pool.hit_t[slot], best.t);
-                    stnt(&pool.hit_prim[slot], (uint32_t)(best.id));
-                } else {   // phase-A best parked in the pool (plain store: re-read by phase B of this block)
-                    pool.hit_t[slot] = best.t;
-                    pool.hit_prim[slot] = best.id;
+                id_a = best.id;
+                if (n_my > 0) {   // phase-A best waits in LDS for phase B
+                    s_best_t[sl] = best.t;
                     s_nitems[sl] = (uint8_t)n_my;
                 }
             }
+            s_best_id[sl] = id_a;
             // compact the rays that recorded meshes (slot order inside a wave is kept)
             const unsigned long long m = __ballot(n_my > 0);
             if (m) {
@@ -395,16 +434,20 @@ __global__ __launch_bounds__(BLOCK, 4) void k_extend2(SceneD sc, PoolD pool, Cou
             const uint32_t idx = g * 64u + (uint32_t)lane;
             if (idx < n_rays) {
                 const uint32_t sl = s_rays[idx], slot = wbase + sl;
-                const RayD r{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, ldnt(&pool.time[slot])};
-                Closest best{pool.hit_t[slot], pool.hit_prim[slot]};
+                const RayD r = load_ray(pool, slot);
+                Closest best{s_best_t[sl], s_best_id[sl]};
                 const uint32_t n_my = s_nitems[sl];
                 for (uint32_t k = 0; k < n_my; ++k) {
                     const Entry e = sc.entries[s_items[sl * EXT_MAXI + k]];
                     blas_pass(sc, r, e, t_min, t_min_f, stk, EXT_STACK, best);
                 }
-                stnt(&pool.hit_t[slot], best.t);
-                stnt(&pool.hit_prim[slot], (uint32_t)(best.id));
+                s_best_id[sl] = best.id;
             }
+        }
+        __syncthreads();
+        for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) {   // the window's result: one coalesced 4-byte store per slot
+            const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x;
+            stnt(&pool.hit_prim[wbase + sl], s_best_id[sl]);
         }
         __syncthreads();   // LDS lists are reused by the next window
     }
@@ -422,6 +465,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
     uint32_t* stk = &stack[threadIdx.x];
     const int lane = (int)(threadIdx.x & 63u);
     const double t_min = 1e-3;                                    // camera.rs:171,179
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
 
     // this wave's contiguous share of the pool (multiples of 64 slots); refills walk it with a
     // wave-uniform cursor — no atomics
@@ -450,7 +494,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
                 const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (idx < cursor_end && pool.bounce[idx] < SLOT_IDLE) {
                     slot = (uint32_t)idx;
-                    r = RayD{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, ldnt(&pool.time[slot])};
+                    r = load_ray(pool, slot);
                     f = make_rayf(r.o, r.d, sc.tlas_extent);
                     best = Closest{D_INF, HIT_NONE};
                     t_max_f = t_max_f32(best.t);
@@ -499,12 +543,11 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
                 t_max_f = t_max_f32(best.t);
             }
         } else if (cur == REF_LEAVE_INSTANCE) {                   // back to world space: reload the ray
-            r = RayD{V3{ldnt(&pool.ox[slot]), ldnt(&pool.oy[slot]), ldnt(&pool.oz[slot])}, V3{ldnt(&pool.dx[slot]), ldnt(&pool.dy[slot]), ldnt(&pool.dz[slot])}, r.time};
+            r = load_ray(pool, slot);
             f = make_rayf(r.o, r.d, sc.tlas_extent);
         }
         if (pop) {
             if (sp == 0) {
-                stnt(&pool.hit_t[slot], best.t);
                 stnt(&pool.hit_prim[slot], (uint32_t)(best.id));
                 active = false;
             } else {
@@ -523,16 +566,18 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     const bool alive = bounce != SLOT_DEAD;
     const bool was_idle = bounce == SLOT_IDLE;
     bool finished = was_idle;
-    uint32_t pixel = 0;
+    uint32_t pixel = 0, sample = 0;
     RayD ray{};
     V3 thr{}, rad{};
     Rng rng{};
     if (alive && !was_idle) {
-        pixel = pool.dynamic ? pool.pixel[s] : s % pool.n_pixels;
-        ray = RayD{V3{pool.ox[s], pool.oy[s], pool.oz[s]}, V3{pool.dx[s], pool.dy[s], pool.dz[s]}, pool.time[s]};
-        thr = V3{pool.tx[s], pool.ty[s], pool.tz[s]};
-        rad = V3{pool.rx[s], pool.ry[s], pool.rz[s]};
-        rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, pool.sample[s], pool.draw[s]};
+        const PathS q = load_path(pool, s);
+        pixel = pool.dynamic ? q.pixel : s % pool.n_pixels;
+        sample = q.sample;
+        ray = load_ray(pool, s);
+        thr = q.thr;
+        rad = q.rad;
+        rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, q.draw};
         const uint32_t gid = pool.hit_prim[s];
         HitD hit;
         if (gid == HIT_NONE || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
@@ -603,7 +648,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         }
     } else if (alive && finished) {
         pool.ax[s] += rad.x; pool.ay[s] += rad.y; pool.az[s] += rad.z;
-        next_sample = pool.sample[s] + pool.k;
+        next_sample = sample + pool.k;
         more = next_sample < pool.spp_end;
     }
     if (alive && finished) {
@@ -616,8 +661,8 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             thr = V3{1.0, 1.0, 1.0};
             rad = V3{0.0, 0.0, 0.0};
             bounce = 0;
-            pool.sample[s] = next_sample;
-            if (pool.dynamic) pool.pixel[s] = next_pixel;
+            sample = next_sample;
+            pixel = next_pixel;
         } else {
             bounce = SLOT_DEAD;
             ++n_died;
@@ -626,12 +671,8 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     if (alive) {
         pool.bounce[s] = bounce;
         if (bounce < SLOT_IDLE) {
-            pool.ox[s] = ray.o.x; pool.oy[s] = ray.o.y; pool.oz[s] = ray.o.z;
-            pool.dx[s] = ray.d.x; pool.dy[s] = ray.d.y; pool.dz[s] = ray.d.z;
-            pool.time[s] = ray.time;
-            pool.tx[s] = thr.x; pool.ty[s] = thr.y; pool.tz[s] = thr.z;
-            pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z;
-            pool.draw[s] = rng.draw;
+            store_ray(pool, s, ray);
+            store_path(pool, s, PathS{thr, rad, sample, rng.draw, pixel});
         }
     }
 }
@@ -649,6 +690,7 @@ template <bool SORT, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     unsigned long long n_done = 0, n_died = 0;
     const int lane = (int)(threadIdx.x & 63u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_extend = 0;
     if (!SORT) {
         // n_alloc is a multiple of 256: whole waves run every chunk (wave ballots inside shade_slot)
         for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK)
@@ -660,8 +702,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
         __shared__ uint32_t s_hist[NCLASS], s_next;
         constexpr int PER = SORT_WINDOW / BLOCK, NGRP = SORT_WINDOW / 64;
         const int wave = (int)(threadIdx.x >> 6);
-        for (uint32_t wbase = blockIdx.x * SORT_WINDOW; wbase < pool.n_alloc; wbase += gridDim.x * SORT_WINDOW) {
-            if (threadIdx.x == 0) s_next = 0;
+        __shared__ uint32_t s_win;
+        const uint32_t n_windows = pool.n_alloc / SORT_WINDOW;
+        for (;;) {
+            if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_shade, 1ull); s_next = 0; }
+            __syncthreads();
+            if (s_win >= n_windows) break;
+            const uint32_t wbase = s_win * SORT_WINDOW;
             // classify; STABLE counting sort (slot order is kept inside a class, so the work items a
             // wave dequeues — consecutive pixels of one tile — land in neighbouring slots and the next
             // k_extend sees coherent primary rays)
@@ -814,8 +861,17 @@ static inline dim3 grid_for(uint32_t n, int max_blocks) {
 void launch_init(const CamD& cam, const PoolD& pool, uint64_t seed, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_init, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, cam, pool, seed);
 }
+typedef void (*extend2_fn)(SceneD, PoolD, CountersD*);
+static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min blocks per CU
+    switch (code) {
+    case 203: return k_extend2<20, 3>;
+    case 204: return k_extend2<20, 4>;
+    case 242: return k_extend2<24, 2>;
+    default: return k_extend2<24, 3>;
+    }
+}
 void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int fetch_threshold, hipStream_t st) {
-    if (fetch_threshold == 0) hipLaunchKernelGGL(k_extend2, grid_for((pool.n_alloc / EXT_WINDOW) * BLOCK, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    if (fetch_threshold <= -100) hipLaunchKernelGGL(pick_extend2(-fetch_threshold), grid_for((pool.n_alloc / EXT_WINDOW) * BLOCK, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
     else if (fetch_threshold < 0) hipLaunchKernelGGL(k_extend, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
     else hipLaunchKernelGGL(k_extend_fetch, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt, fetch_threshold);
 }
@@ -848,7 +904,7 @@ void launch_math_probe(int which, const double* in, uint32_t n, double* out, hip
 }
 int kernel_occupancy_blocks(int which, int variant) {
     int nb = 0;
-    const void* f = which == 0 ? (variant > 0 ? (const void*)k_extend_fetch : variant < 0 ? (const void*)k_extend : (const void*)k_extend2) : (const void*)pick_shade(variant);
+    const void* f = which == 0 ? (variant > 0 ? (const void*)k_extend_fetch : variant <= -100 ? (const void*)pick_extend2(-variant) : (const void*)k_extend) : (const void*)pick_shade(variant);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

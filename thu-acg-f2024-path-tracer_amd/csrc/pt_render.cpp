@@ -219,7 +219,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const uint32_t n_slots = (uint32_t)n_slots64;
     // one allocation, carved into the SoA arrays (17 f64 + 5 u32 per slot)
     const size_t n_al = ((size_t)n_slots + 2047) & ~(size_t)2047;   // whole 2048-slot windows (k_shade sorts per window)
-    const size_t bytes = n_al * (17 * sizeof(double) + 5 * sizeof(uint32_t));
+    const size_t bytes = n_al * (sizeof(RayRec) + sizeof(PathRec) + 3 * sizeof(double) + 2 * sizeof(uint32_t));
     if (bytes > s->pool_bytes) {
         if (s->pool_mem) (void)hipFree(s->pool_mem);
         s->pool_mem = nullptr;
@@ -234,12 +234,14 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     PoolD pool;
     memset(&pool, 0, sizeof pool);
     {
-        double* d = (double*)s->pool_mem;
-        double** f64s[17] = {&pool.ox, &pool.oy, &pool.oz, &pool.dx, &pool.dy, &pool.dz, &pool.time, &pool.tx, &pool.ty,
-                             &pool.tz, &pool.rx, &pool.ry, &pool.rz, &pool.ax, &pool.ay, &pool.az, &pool.hit_t};
+        char* m = (char*)s->pool_mem;   // hipMalloc memory is 256-B aligned; records first (64-B aligned)
+        pool.ray = (RayRec*)m; m += n_al * sizeof(RayRec);
+        pool.path = (PathRec*)m; m += n_al * sizeof(PathRec);
+        double* d = (double*)m;
+        double** f64s[3] = {&pool.ax, &pool.ay, &pool.az};
         for (auto p : f64s) { *p = d; d += n_al; }
         uint32_t* u = (uint32_t*)d;
-        uint32_t** u32s[5] = {&pool.hit_prim, &pool.sample, &pool.bounce, &pool.draw, &pool.pixel};
+        uint32_t** u32s[2] = {&pool.hit_prim, &pool.bounce};
         for (auto p : u32s) { *p = u; u += n_al; }
     }
     pool.n_slots = n_slots;
@@ -268,16 +270,27 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     if (const char* e = getenv("PT_GRID_MULT")) mult = std::max(1, atoi(e));
     int shade_variant = 12;   // k_shade<sort, min waves/SIMD>: sort*10 + waves (12 = windowed material sort, 2 = plain)
     if (const char* e = getenv("PT_SHADE_VARIANT")) shade_variant = atoi(e);
-    // two-phase K2 pays only when there are meshes to defer, and its short LDS stack must fit the scene's BVHs
-    int fetch_threshold = (s->n_mesh_entries > 0 && s->stack_need <= (uint32_t)EXTEND2_STACK_ENTRIES) ? 0 : -1;
-    if (const char* e = getenv("PT_FETCH_THRESHOLD")) fetch_threshold = std::min(64, std::max(-1, atoi(e)));
-    if (fetch_threshold == 0 && s->stack_need > (uint32_t)EXTEND2_STACK_ENTRIES) fetch_threshold = -1;
+    // K2 variant: two-phase kernel when there are meshes to defer and its LDS stack covers the scene's BVHs, else the
+    // batch kernel. PT_FETCH_THRESHOLD overrides: 0 = two-phase, -1 = batch, n in 1..64 = dynamic-fetch kernel refilling a
+    // wave when >= n lanes are idle (experimental); PT_EXT2 = stack*10 + blocks per CU picks the instantiation.
+    auto extend2_code = [&]() -> int {
+        if (s->stack_need > (uint32_t)EXTEND2_STACK_LARGE) return 0;
+        int code = s->stack_need <= (uint32_t)EXTEND2_STACK_SMALL ? 204 : 243;
+        if (const char* e = getenv("PT_EXT2")) {
+            const int c = atoi(e);
+            if (c / 10 >= (int)s->stack_need && (c == 203 || c == 204 || c == 242 || c == 243)) code = c;
+        }
+        return code;
+    };
+    int fetch_threshold = (s->n_mesh_entries > 0 && extend2_code() != 0) ? -extend2_code() : -1;
+    if (const char* e = getenv("PT_FETCH_THRESHOLD")) {
+        const int v = std::min(64, std::max(-1, atoi(e)));
+        fetch_threshold = v == 0 ? (extend2_code() != 0 ? -extend2_code() : -1) : v;
+    }
     const int blocks_extend = kernel_occupancy_blocks(0, fetch_threshold), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;
-    // K2 variant (PT_FETCH_THRESHOLD): 0 = two-phase kernel (default with meshes); -1 = batch kernel (default without); n in 1..64 =
-    // persistent dynamic-fetch kernel refilling a wave when >= n lanes are idle (experimental)
     CountersD init_cnt;
     memset(&init_cnt, 0, sizeof init_cnt);
     init_cnt.alive = spp == 0 ? 0 : n_slots;   // every slot starts with one sample (k <= spp / n_slots <= total_work)
@@ -354,7 +367,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         stats->ms_other = timer.ms[2];
         stats->launches_extend = timer.launches[0];
         stats->launches_shade = timer.launches[1];
-        stats->extend_variant = fetch_threshold == 0 ? 0u : fetch_threshold < 0 ? 1u : 2u;
+        stats->extend_variant = fetch_threshold <= -100 ? 0u : fetch_threshold < 0 ? 1u : 2u;
         stats->shade_variant = (uint32_t)shade_variant;
         stats->blocks_extend = (uint32_t)grid_extend;
         stats->blocks_shade = (uint32_t)grid_shade;

@@ -126,15 +126,23 @@ struct SceneD {
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 constexpr uint32_t SLOT_DEAD = 0xFFFFFFFFu;   // value of `bounce` for a finished slot
 constexpr uint32_t SLOT_IDLE = 0xFFFFFFFEu;   // dynamic mode: drew an item outside the image, draws again next iteration
+// Path state is kept as two 64-byte records per slot (array of structures): k_shade visits slots in
+// material-class order and k_extend2's mesh pass visits them compacted, i.e. both PERMUTED inside a
+// window — with one array per field every wave touched 1/8 of many 128-B lines and the rest of each
+// line had left the L2 before the wave that needed it came by (measured 2.6 GB of HBM traffic per
+// k_shade launch for 1.1 GB of state). A record is read/written whole by its own lane (4 x 16 B).
+struct alignas(64) RayRec { double ox, oy, oz, dx, dy, dz, time, pad; };   // current ray (direction normalised)
+struct alignas(64) PathRec {
+    double tx, ty, tz;                            // throughput
+    double rx, ry, rz;                            // radiance of the sample in flight
+    uint32_t sample, draw, pixel, pad;            // sample index, RNG draw counter, pixel (dynamic mode)
+};
 struct PoolD {
-    double *ox, *oy, *oz, *dx, *dy, *dz, *time;   // current ray (direction normalised)
-    double *tx, *ty, *tz;                         // throughput
-    double *rx, *ry, *rz;                         // radiance of the sample in flight
-    double *ax, *ay, *az;                         // sum over this slot's finished samples
-    double* hit_t;
+    RayRec* ray;
+    PathRec* path;
+    double *ax, *ay, *az;                         // static mode: sum over this slot's finished samples
     uint32_t* hit_prim;
-    uint32_t *sample, *bounce, *draw;
-    uint32_t* pixel;                              // dynamic mode: pixel of the sample in flight
+    uint32_t* bounce;                             // bounce count, or SLOT_DEAD / SLOT_IDLE
     double* accum;                                // dynamic mode: frame accumulator (W*H*3 sums)
     unsigned long long total_work;                // dynamic mode: n_pixels * (spp_end - spp_begin)
     uint32_t n_slots, n_pixels, k;                // k = slots per pixel (static mode)
@@ -152,7 +160,11 @@ struct CountersD {
     unsigned long long alive;        // slots still rendering
     unsigned long long segments;     // extend() calls on live paths
     unsigned long long samples;      // finished samples
-    unsigned long long pad[13];
+    // window queues of k_extend2 / k_shade<sort>: blocks draw the next window of the pool from these instead
+    // of striding over it (window costs differ by an order of magnitude between sky and mesh tiles). Each
+    // kernel zeroes the OTHER kernel's queue; the two alternate on one stream.
+    unsigned long long win_extend, win_shade;
+    unsigned long long pad[11];
     struct alignas(128) Shard { unsigned long long next; unsigned long long pad[15]; } work[WORK_SHARDS];
 };
 

@@ -8,7 +8,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]; tag = sys.argv[2]
 def short(name):
-    for k in ("k_extend", "k_shade", "k_init", "k_resolve", "k_compact"):
+    for k in ("k_extend_tlas", "k_extend_mesh", "k_extend", "k_shade", "k_init", "k_resolve", "k_compact"):
         if k in name: return k
     return None
 vals = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> per-dispatch values (summed over dims)
@@ -32,14 +32,14 @@ for k, cs in vals.items():
 slots = 4194304
 cal = {}
 if "k_init" in out and "WRITE_SIZE" in out["k_init"]:
-    known = slots * (14 * 8 + 5 * 4)                      # k_init writes 14 f64 + 5 u32 per slot
+    known = slots * (64 + 64 + 8 + 4 + 4)                 # k_init writes RayRec + PathRec + hit_t + hit_prim + bounce per slot
     cal["write_factor"] = known / (out["k_init"]["WRITE_SIZE"]["first"] * 1024)
 if "k_extend" in out and "FETCH_SIZE" in out["k_extend"]:
-    known = slots * (7 * 8 + 4)                           # first k_extend launch: every slot alive, ray (7 f64) + bounce
+    known = slots * (64 + 4)                              # first k_extend launch: every slot alive, RayRec + bounce
     cal["fetch_factor_first_extend"] = known / (out["k_extend"]["FETCH_SIZE"]["first"] * 1024)
 out["calibration"] = cal
 ff = 2.0    # guide: FETCH_SIZE reads exactly 1/2 of wide coalesced streams on gfx950
-for k in ("k_extend", "k_shade"):
+for k in ("k_extend", "k_extend_tlas", "k_extend_mesh", "k_shade"):
     if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
         f = out[k]["FETCH_SIZE"]["mean"] * 1024 * ff; w = out[k]["WRITE_SIZE"]["mean"] * 1024
         out[k]["hbm_bytes_per_launch"] = f + w
@@ -60,7 +60,7 @@ for k in ("k_extend", "k_shade"):
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 for name in (f"{tag}_pmc_summary.json", "pmc_latest.json"):
     json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
-for k in ("k_extend", "k_shade"):
+for k in ("k_extend", "k_extend_tlas", "k_extend_mesh", "k_shade"):
     if k in out:
         print(k, json.dumps({x: out[k][x] for x in out[k] if x in ("hbm_bytes_per_launch", "derived", "l2_hit_rate")}, indent=1))
 print("calibration", cal)
