@@ -28,9 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0    # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s peak, ~6.3 achievable)
-# algorithmic bytes: f64 path record = 13 f64 + 3 u32 = 116 B
-B_EXTEND_PER_SEGMENT = 56 + 12           # ray in (7 f64) + hit out (t f64 + prim u32)
-B_SHADE_PER_SEGMENT = 116 + 12 + 116     # record in + hit in + record out
+# algorithmic bytes: f64 path record = ray 7 f64 + throughput 3 f64 + (sample, draw, pixel) 3 u32 = 92 B
+B_EXTEND_PER_SEGMENT = 56 + 4            # ray in (7 f64) + closest primitive out (u32)
+B_SHADE_PER_SEGMENT = 92 + 4 + 92        # record in + closest primitive in + record out
 B_FB_PER_SAMPLE = 24                     # 3 f64 accumulator add per finished sample
 
 

@@ -15,7 +15,6 @@ void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out,
 void launch_math_probe(int which, const double* in, uint32_t n, double* out, hipStream_t st);
 // K2 variant code (`fetch_threshold` of launch_extend / kernel_occupancy_blocks): -1 = batch kernel,
 // 1..64 = dynamic-fetch kernel with that refill threshold, -(stack*10 + blocks) = two-phase kernel
-// k_extend2<stack, blocks> for stack in {20, 24}.
-constexpr int EXTEND2_STACK_SMALL = 20, EXTEND2_STACK_LARGE = 24;
+// k_extend2<stack, blocks> for stack in {16, 20, 24}.
 int kernel_occupancy_blocks(int which, int variant);   // 0 = extend, 1 = shade; resident blocks per CU
 }  // namespace pt

@@ -24,7 +24,7 @@ constexpr int BLOCK = 256;
 template <class T> PT_DEV T ldnt(const T* p) { return __builtin_nontemporal_load(p); }
 template <class T> PT_DEV void stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
-// ---- path records (pt_types.h RayRec / PathRec): one lane moves one whole 64-byte record --------
+// ---- path records (pt_types.h RayRec / PathRec): one lane moves one whole record, 16 B per access ----
 typedef double d2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 PT_DEV RayD load_ray(const PoolD& pool, uint32_t s) {
@@ -32,26 +32,32 @@ PT_DEV RayD load_ray(const PoolD& pool, uint32_t s) {
     const d2v a = p[0], b = p[1], c = p[2], d = p[3];
     return RayD{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, d.x};
 }
-PT_DEV void store_ray(const PoolD& pool, uint32_t s, const RayD& r) {
+PT_DEV RayD load_ray(const PoolD& pool, uint32_t s, uint32_t& sample, uint32_t& draw) {
+    const d2v* p = reinterpret_cast<const d2v*>(&pool.ray[s]);
+    const d2v a = p[0], b = p[1], c = p[2];
+    const u4v d = *reinterpret_cast<const u4v*>(p + 3);
+    sample = d.z;
+    draw = d.w;
+    return RayD{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, __hiloint2double((int)d.y, (int)d.x)};
+}
+PT_DEV void store_ray(const PoolD& pool, uint32_t s, const RayD& r, uint32_t sample, uint32_t draw) {
     d2v* p = reinterpret_cast<d2v*>(&pool.ray[s]);
     p[0] = d2v{r.o.x, r.o.y};
     p[1] = d2v{r.o.z, r.d.x};
     p[2] = d2v{r.d.y, r.d.z};
-    p[3] = d2v{r.time, 0.0};
+    *reinterpret_cast<u4v*>(p + 3) = u4v{(uint32_t)__double2loint(r.time), (uint32_t)__double2hiint(r.time), sample, draw};
 }
-struct PathS { V3 thr, rad; uint32_t sample, draw, pixel; };
-PT_DEV PathS load_path(const PoolD& pool, uint32_t s) {
+PT_DEV V3 load_path(const PoolD& pool, uint32_t s, uint32_t& pixel) {
     const d2v* p = reinterpret_cast<const d2v*>(&pool.path[s]);
-    const d2v a = p[0], b = p[1], c = p[2];
-    const u4v u = *reinterpret_cast<const u4v*>(p + 3);
-    return PathS{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, u.x, u.y, u.z};
+    const d2v a = p[0];
+    const u4v b = *reinterpret_cast<const u4v*>(p + 1);
+    pixel = b.z;
+    return V3{a.x, a.y, __hiloint2double((int)b.y, (int)b.x)};
 }
-PT_DEV void store_path(const PoolD& pool, uint32_t s, const PathS& q) {
+PT_DEV void store_path(const PoolD& pool, uint32_t s, V3 thr, uint32_t pixel) {
     d2v* p = reinterpret_cast<d2v*>(&pool.path[s]);
-    p[0] = d2v{q.thr.x, q.thr.y};
-    p[1] = d2v{q.thr.z, q.rad.x};
-    p[2] = d2v{q.rad.y, q.rad.z};
-    *reinterpret_cast<u4v*>(p + 3) = u4v{q.sample, q.draw, q.pixel, 0u};
+    p[0] = d2v{thr.x, thr.y};
+    *reinterpret_cast<u4v*>(p + 1) = u4v{(uint32_t)__double2loint(thr.z), (uint32_t)__double2hiint(thr.z), pixel, 0u};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -251,20 +257,18 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
             sample = pool.spp_begin + s / pool.n_pixels;
             has_work = s < pool.n_slots && sample < pool.spp_end;
             pool.ax[s] = 0.0; pool.ay[s] = 0.0; pool.az[s] = 0.0;
+            pool.rx[s] = 0.0; pool.ry[s] = 0.0; pool.rz[s] = 0.0;
         }
         pool.hit_prim[s] = HIT_NONE;
-        PathS q{V3{1.0, 1.0, 1.0}, V3{0.0, 0.0, 0.0}, sample, 0u, pixel};
+        store_path(pool, s, V3{1.0, 1.0, 1.0}, pixel);
         if (!has_work || idle) {
             pool.bounce[s] = idle ? SLOT_IDLE : SLOT_DEAD;
-            store_path(pool, s, q);
-            store_ray(pool, s, RayD{});
+            store_ray(pool, s, RayD{}, sample, 0u);
             continue;
         }
         Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, 0u};
         RayD r = generate_ray(cam, pixel / cam.width, pixel % cam.width, rng);
-        q.draw = rng.draw;
-        store_ray(pool, s, r);
-        store_path(pool, s, q);
+        store_ray(pool, s, r, sample, rng.draw);
         pool.bounce[s] = 0;
     }
 }
@@ -302,9 +306,12 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 // The phase-A best hit of a ray waits in LDS (t and id), and the window's final primitive ids leave
 // with ONE coalesced store per slot: k_shade re-intersects the primitive (reconstruct_hit) and never
 // needs t, so 4 B per slot is all this kernel writes.
-// LDS per block: STACK x 1 KB (traversal stacks) + 19 KB; STACK = 20 gives 39 KB = 4 blocks per CU,
-// STACK = 24 gives 43 KB = 3 blocks per CU. The host picks the smallest STACK that covers the scene's
-// BVHs (pt_scene::stack_need); deeper scenes use the batch kernel.
+// LDS per block: STACK x 1 KB (traversal stacks) + 19 KB, STACK in {16, 20, 24}: the host picks the
+// smallest that covers the scene (pt_scene::stack_need_extend2 — only the deepest mesh tree when the top
+// level is walked flat); deeper scenes use the batch kernel. The kernel runs three blocks per CU: a
+// fourth would cap it at 128 registers and the spills cost more than the extra waves bring (measured).
+// Tried and dropped: the two phases as two kernels with a global candidate list; every
+// wave on its own 256-slot window without block barriers; warming the next window's ray lines.
 constexpr int EXT_WINDOW = 1024, EXT_MAXI = 4;
 
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
@@ -361,17 +368,57 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         if (s_win >= n_windows) break;
         const uint32_t wbase = s_win * EXT_WINDOW;
         // ---- phase A: top-level tree only --------------------------------------------------------
+        // the ray of the NEXT chunk is requested before this chunk's traversal starts: with three waves per
+        // SIMD nothing else hides the 2-3 us an HBM fetch takes
+        bool alive_next = pool.bounce[wbase + threadIdx.x] < SLOT_IDLE;
+        RayD r_next{};
+        if (alive_next) r_next = load_ray(pool, wbase + threadIdx.x);
         for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) {
-            const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x, slot = wbase + sl;
-            const bool alive = pool.bounce[slot] < SLOT_IDLE;
+            const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x;
+            const bool alive = alive_next;
+            const RayD r = r_next;
+            if (j + 1 < EXT_WINDOW / BLOCK) {
+                alive_next = pool.bounce[wbase + sl + BLOCK] < SLOT_IDLE;
+                if (alive_next) r_next = load_ray(pool, wbase + sl + BLOCK);
+            }
             uint32_t n_my = 0;
-            uint32_t id_a = HIT_NONE;
+            RayF f{};
+            Closest best{D_INF, HIT_NONE};
+            float t_max_f = t_max_f32(best.t);
             if (alive) {
                 ++nseg;
-                const RayD r = load_ray(pool, slot);
-                const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
-                Closest best{D_INF, HIT_NONE};
-                float t_max_f = t_max_f32(best.t);
+                f = make_rayf(r.o, r.d, sc.tlas_extent);
+            }
+            // one world entry whose box the ray enters: meshes are recorded, everything else is tested on the spot
+            auto visit_entry = [&](uint32_t ei, const Entry& e, int sp) {
+                if (e.kind == ENTRY_MESH) {
+                    if (n_my < (uint32_t)EXT_MAXI && ei <= 0xFFu) {
+                        s_items[sl * EXT_MAXI + n_my++] = (uint8_t)ei;            // defer to phase B
+                    } else {
+                        blas_pass(sc, r, e, t_min, t_min_f, stk + (size_t)sp * BLOCK, EXT_STACK - sp, best);   // overflow: walk it now
+                        t_max_f = t_max_f32(best.t);
+                    }
+                } else {
+                    RayD lr = r;
+                    if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
+                    const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;       // cuboid.rs: six quads, linear
+                    for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+                    t_max_f = t_max_f32(best.t);
+                }
+            };
+            if (sc.tlas_flat) {
+                // Small top level: the wave walks the ENTRY LIST together instead of each lane walking the tree.
+                // The entry index is wave-uniform, so boxes, entries and instance transforms arrive by scalar
+                // loads, there is no stack, and an entry no lane's ray enters costs one box test.
+                for (uint32_t ei = 0; ei < sc.n_entries; ++ei) {
+                    const float* bx = sc.entry_box + 6u * ei;
+                    float tn;
+                    const bool hb = alive && slab_f32(bx, bx + 3, f, t_min_f, t_max_f, tn);
+                    if (__ballot(hb) == 0ull) continue;
+                    const Entry e = sc.entries[ei];
+                    if (hb) visit_entry(ei, e, 0);
+                }
+            } else if (alive) {
                 int sp = 0;
                 uint32_t cur = sc.tlas_root;
                 for (;;) {
@@ -385,32 +432,16 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                         }
                     } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
                         const uint32_t ei = cur & 0x3FFFFFFFu;
-                        const Entry e = sc.entries[ei];
-                        if (e.kind == ENTRY_MESH) {
-                            if (n_my < (uint32_t)EXT_MAXI && ei <= 0xFFu) {
-                                s_items[sl * EXT_MAXI + n_my++] = (uint8_t)ei;            // defer to phase B
-                            } else {
-                                blas_pass(sc, r, e, t_min, t_min_f, stk + (size_t)sp * BLOCK, EXT_STACK - sp, best);   // overflow: walk it now
-                                t_max_f = t_max_f32(best.t);
-                            }
-                        } else {
-                            RayD lr = r;
-                            if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
-                            const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;       // cuboid.rs: six quads, linear
-                            for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
-                            t_max_f = t_max_f32(best.t);
-                        }
-                    } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
-                        // cannot happen at the top level (meshes are entries); kept for completeness
+                        visit_entry(ei, sc.entries[ei], sp);
                     }
                     if (sp == 0) break;
                     cur = stk[(--sp) * BLOCK];
                 }
-                id_a = best.id;
-                if (n_my > 0) {   // phase-A best waits in LDS for phase B
-                    s_best_t[sl] = best.t;
-                    s_nitems[sl] = (uint8_t)n_my;
-                }
+            }
+            const uint32_t id_a = alive ? best.id : HIT_NONE;
+            if (n_my > 0) {   // phase-A best waits in LDS for phase B
+                s_best_t[sl] = best.t;
+                s_nitems[sl] = (uint8_t)n_my;
             }
             s_best_id[sl] = id_a;
             // compact the rays that recorded meshes (slot order inside a wave is kept)
@@ -560,9 +591,23 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, C
 
 // K3: the body of camera.rs:177-226 for the path in slot `s`, executed by all 64 lanes of a wave
 // together (it contains wave-level ballots for the work-counter dequeue, K5).
-PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane,
+// color += throughput * emitted (camera.rs:182,187). Static mode: into the sample's own sum, which reaches
+// the pixel when the sample ends (the reference's order of additions). Dynamic mode: straight into the
+// frame accumulator — exact zeros are skipped, NaN/inf are not (they poison the pixel like they do there).
+PT_DEV void add_radiance(const PoolD& pool, uint32_t pixel, V3& rad, V3 c) {
+    if (!pool.dynamic) {
+        rad = rad + c;
+    } else if (!(c.x == 0.0 && c.y == 0.0 && c.z == 0.0)) {
+        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], c.x);
+        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], c.y);
+        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], c.z);
+    }
+}
+
+// `enable` = false makes the lane a bystander that only takes part in the wave ballots.
+PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane, bool enable,
                        unsigned long long& n_done, unsigned long long& n_died) {
-    uint32_t bounce = pool.bounce[s];
+    uint32_t bounce = enable ? pool.bounce[s] : SLOT_DEAD;
     const bool alive = bounce != SLOT_DEAD;
     const bool was_idle = bounce == SLOT_IDLE;
     bool finished = was_idle;
@@ -571,24 +616,25 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     V3 thr{}, rad{};
     Rng rng{};
     if (alive && !was_idle) {
-        const PathS q = load_path(pool, s);
-        pixel = pool.dynamic ? q.pixel : s % pool.n_pixels;
-        sample = q.sample;
-        ray = load_ray(pool, s);
-        thr = q.thr;
-        rad = q.rad;
-        rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, q.draw};
+        uint32_t draw;
+        thr = load_path(pool, s, pixel);
+        if (!pool.dynamic) {
+            pixel = s % pool.n_pixels;
+            rad = V3{pool.rx[s], pool.ry[s], pool.rz[s]};
+        }
+        ray = load_ray(pool, s, sample, draw);
+        rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, draw};
         const uint32_t gid = pool.hit_prim[s];
         HitD hit;
         if (gid == HIT_NONE || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
-            rad = rad + thr * sample_environment(sc, cam, ray.d);   // camera.rs:180-183
+            add_radiance(pool, pixel, rad, thr * sample_environment(sc, cam, ray.d));   // camera.rs:180-183
             finished = true;
         } else {
             const MatD& m = sc.mats[hit.mat];
             // camera.rs:186-187 — added for every material (zero unless emissive) so that a
             // non-finite throughput poisons the sample exactly as it does in the reference
             V3 emission = m.kind == MAT_LIGHT ? tex_rgb(sc, m.color_tex, hit.u, hit.v, hit.point) : V3{0.0, 0.0, 0.0};
-            rad = rad + thr * emission;
+            add_radiance(pool, pixel, rad, thr * emission);
             if (bounce > 5) {                                        // russian roulette :190-196
                 double p = clampd(luminance(thr), 0.01, 1.0);
                 if (rng_f64(rng) > p) finished = true;
@@ -635,11 +681,6 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             base = __shfl(base, leader);
             if (alive && finished) {
                 const unsigned long long w = shard_item(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)), shard);
-                if (!was_idle) {
-                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], rad.x);
-                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], rad.y);
-                    unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], rad.z);
-                }
                 if (w < pool.total_work) {
                     more = true;
                     next_idle = !work_to_pixel(pool, w, next_pixel, next_sample);
@@ -671,8 +712,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     if (alive) {
         pool.bounce[s] = bounce;
         if (bounce < SLOT_IDLE) {
-            store_ray(pool, s, ray);
-            store_path(pool, s, PathS{thr, rad, sample, rng.draw, pixel});
+            store_ray(pool, s, ray, sample, rng.draw);
+            store_path(pool, s, thr, pixel);
+            if (!pool.dynamic) { pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z; }
         }
     }
 }
@@ -694,7 +736,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
     if (!SORT) {
         // n_alloc is a multiple of 256: whole waves run every chunk (wave ballots inside shade_slot)
         for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK)
-            shade_slot(sc, cam, pool, cnt, seed, base + threadIdx.x, lane, n_done, n_died);
+            shade_slot(sc, cam, pool, cnt, seed, base + threadIdx.x, lane, true, n_done, n_died);
     } else {
         __shared__ uint16_t s_perm[SORT_WINDOW];
         constexpr uint32_t NCLASS = 3u + MAT_KINDS, K_IDLE = 1u + MAT_KINDS, K_DEAD = 2u + MAT_KINDS;   // miss, one per material kind, idle, dead
@@ -768,8 +810,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 if (lane == 0) g = atomicAdd(&s_next, 1u);
                 g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
                 if (g * 64u >= n_live) break;
-                // lanes past n_live in the last group land on dead slots (sorted last): a no-op
-                shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[g * 64u + lane], lane, n_done, n_died);
+                // lanes past n_live in the last group are bystanders
+                shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[g * 64u + lane], lane, g * 64u + (uint32_t)lane < n_live, n_done, n_died);
             }
             __syncthreads();   // LDS is reused by the next window
         }
@@ -864,6 +906,8 @@ void launch_init(const CamD& cam, const PoolD& pool, uint64_t seed, int max_bloc
 typedef void (*extend2_fn)(SceneD, PoolD, CountersD*);
 static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min blocks per CU
     switch (code) {
+    case 163: return k_extend2<16, 3>;
+    case 164: return k_extend2<16, 4>;
     case 203: return k_extend2<20, 3>;
     case 204: return k_extend2<20, 4>;
     case 242: return k_extend2<24, 2>;

@@ -219,7 +219,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const uint32_t n_slots = (uint32_t)n_slots64;
     // one allocation, carved into the SoA arrays (17 f64 + 5 u32 per slot)
     const size_t n_al = ((size_t)n_slots + 2047) & ~(size_t)2047;   // whole 2048-slot windows (k_shade sorts per window)
-    const size_t bytes = n_al * (sizeof(RayRec) + sizeof(PathRec) + 3 * sizeof(double) + 2 * sizeof(uint32_t));
+    const size_t bytes = n_al * (sizeof(RayRec) + sizeof(PathRec) + 6 * sizeof(double) + 2 * sizeof(uint32_t));
     if (bytes > s->pool_bytes) {
         if (s->pool_mem) (void)hipFree(s->pool_mem);
         s->pool_mem = nullptr;
@@ -238,7 +238,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         pool.ray = (RayRec*)m; m += n_al * sizeof(RayRec);
         pool.path = (PathRec*)m; m += n_al * sizeof(PathRec);
         double* d = (double*)m;
-        double** f64s[3] = {&pool.ax, &pool.ay, &pool.az};
+        double** f64s[6] = {&pool.ax, &pool.ay, &pool.az, &pool.rx, &pool.ry, &pool.rz};
         for (auto p : f64s) { *p = d; d += n_al; }
         uint32_t* u = (uint32_t*)d;
         uint32_t** u32s[2] = {&pool.hit_prim, &pool.bounce};
@@ -274,11 +274,12 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     // batch kernel. PT_FETCH_THRESHOLD overrides: 0 = two-phase, -1 = batch, n in 1..64 = dynamic-fetch kernel refilling a
     // wave when >= n lanes are idle (experimental); PT_EXT2 = stack*10 + blocks per CU picks the instantiation.
     auto extend2_code = [&]() -> int {
-        if (s->stack_need > (uint32_t)EXTEND2_STACK_LARGE) return 0;
-        int code = s->stack_need <= (uint32_t)EXTEND2_STACK_SMALL ? 204 : 243;
+        const int need = (int)s->stack_need_extend2;
+        if (need > 24) return 0;
+        int code = need <= 16 ? 163 : need <= 20 ? 203 : 243;   // three blocks per CU: four would cap the kernel at 128 registers and spill
         if (const char* e = getenv("PT_EXT2")) {
             const int c = atoi(e);
-            if (c / 10 >= (int)s->stack_need && (c == 203 || c == 204 || c == 242 || c == 243)) code = c;
+            if (c / 10 >= need && (c == 163 || c == 164 || c == 203 || c == 204 || c == 242 || c == 243)) code = c;
         }
         return code;
     };

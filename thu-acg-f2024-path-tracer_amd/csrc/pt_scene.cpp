@@ -564,6 +564,8 @@ int pt::scene_build(pt_scene* s) {
         tlas_items.push_back(BuildItem{world, world.centroid(), (uint32_t)entries.size()});
         entries.push_back(e);
     }
+    std::vector<Box> entry_boxes(tlas_items.size());
+    for (const BuildItem& it : tlas_items) entry_boxes[it.ref_payload] = it.box;
     // Build the TLAS over world entries (one entry per leaf).
     Builder tl{nodes, tlas_items, 1, MAX_TLAS_DEPTH, false, nullptr};
     Box wb;
@@ -582,12 +584,14 @@ int pt::scene_build(pt_scene* s) {
             atlas.insert(atlas.end(), s->tex[i].image.begin(), s->tex[i].image.end());
         }
     }
+    std::vector<float> entry_box(6 * entries.size());   // tlas_items[i] is entry i (built in entry order, before the builder permutes them)
+    for (size_t i = 0; i < entry_boxes.size(); ++i) Builder::store_box(entry_boxes[i], &entry_box[6 * i], &entry_box[6 * i + 3]);
     SceneD v{};
     DeviceBuffers& dev = s->dev;
     bool ok = upload(dev, nodes, v.nodes) && upload(dev, entries, v.entries) && upload(dev, prims, v.prims) &&
               upload(dev, spheres, v.spheres) && upload(dev, quads, v.quads) && upload(dev, tris, v.tris) &&
               upload(dev, tri_gid, v.tri_gid) && upload(dev, insts, v.insts) && upload(dev, tex, v.tex) &&
-              upload(dev, s->mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, lights, v.lights);
+              upload(dev, s->mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, lights, v.lights) && upload(dev, entry_box, v.entry_box);
     if (ok && any_attr) ok = upload(dev, tri_attr, v.tri_attr);
     if (!ok) {
         dev.release();
@@ -598,6 +602,8 @@ int pt::scene_build(pt_scene* s) {
     v.n_entries = (uint32_t)entries.size();
     v.n_prims = (uint32_t)prims.size();
     v.n_lights = (uint32_t)lights.size();
+    v.tlas_flat = entries.size() <= TLAS_FLAT_MAX && !getenv("PT_NO_FLAT_TLAS") ? 1u : 0u;
+    s->stack_need_extend2 = v.tlas_flat ? (uint32_t)(max_blas_depth + 1) : s->stack_need;
     dev.view = v;
     s->n_prims = v.n_prims;
     s->n_mesh_entries = 0;

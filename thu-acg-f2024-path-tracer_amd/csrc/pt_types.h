@@ -108,7 +108,10 @@ struct SceneD {
     uint32_t tlas_root;          // child reference of the top-level root
     float tlas_extent;           // max |coordinate| of the top-level BVH boxes
     uint32_t n_entries, n_prims, n_lights;
+    const float* entry_box;      // lo[3], hi[3] per entry: its world-space box, padded and rounded outward like the node boxes
+    uint32_t tlas_flat;          // n_entries <= TLAS_FLAT_MAX: k_extend2 walks the entry list instead of the top-level tree
 };
+constexpr uint32_t TLAS_FLAT_MAX = 32;
 
 // ---- path pool (SoA, one slot per resident path) ---------------------------------------
 // Two work-assignment modes:
@@ -126,21 +129,26 @@ struct SceneD {
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 constexpr uint32_t SLOT_DEAD = 0xFFFFFFFFu;   // value of `bounce` for a finished slot
 constexpr uint32_t SLOT_IDLE = 0xFFFFFFFEu;   // dynamic mode: drew an item outside the image, draws again next iteration
-// Path state is kept as two 64-byte records per slot (array of structures): k_shade visits slots in
+// Path state is kept as two records per slot (array of structures): k_shade visits slots in
 // material-class order and k_extend2's mesh pass visits them compacted, i.e. both PERMUTED inside a
 // window — with one array per field every wave touched 1/8 of many 128-B lines and the rest of each
 // line had left the L2 before the wave that needed it came by (measured 2.6 GB of HBM traffic per
-// k_shade launch for 1.1 GB of state). A record is read/written whole by its own lane (4 x 16 B).
-struct alignas(64) RayRec { double ox, oy, oz, dx, dy, dz, time, pad; };   // current ray (direction normalised)
-struct alignas(64) PathRec {
+// k_shade launch for 1.1 GB of state). A record is read/written whole by its own lane (16 B at a time).
+// K2 reads RayRec only; K3 reads and writes both: 96 B in, 96 B out per segment.
+struct alignas(64) RayRec {                       // current ray (direction normalised) + RNG position of the path
+    double ox, oy, oz, dx, dy, dz, time;
+    uint32_t sample, draw;                        // sample index, RNG draw counter
+};
+struct alignas(32) PathRec {
     double tx, ty, tz;                            // throughput
-    double rx, ry, rz;                            // radiance of the sample in flight
-    uint32_t sample, draw, pixel, pad;            // sample index, RNG draw counter, pixel (dynamic mode)
+    uint32_t pixel, pad;                          // dynamic mode: pixel of the sample in flight
 };
 struct PoolD {
     RayRec* ray;
     PathRec* path;
     double *ax, *ay, *az;                         // static mode: sum over this slot's finished samples
+    double *rx, *ry, *rz;                         // static mode: radiance of the sample in flight (camera.rs:172); the dynamic
+                                                  // mode adds every contribution to the frame accumulator right away
     uint32_t* hit_prim;
     uint32_t* bounce;                             // bounce count, or SLOT_DEAD / SLOT_IDLE
     double* accum;                                // dynamic mode: frame accumulator (W*H*3 sums)
