@@ -606,7 +606,7 @@ PT_DEV void add_radiance(const PoolD& pool, uint32_t pixel, V3& rad, V3 c) {
 
 // `enable` = false makes the lane a bystander that only takes part in the wave ballots.
 PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane, bool enable,
-                       unsigned long long& n_done, unsigned long long& n_died) {
+                       uint32_t& shard, unsigned long long& n_done, unsigned long long& n_died) {
     uint32_t bounce = enable ? pool.bounce[s] : SLOT_DEAD;
     const bool alive = bounce != SLOT_DEAD;
     const bool was_idle = bounce == SLOT_IDLE;
@@ -671,20 +671,31 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     uint32_t next_pixel = pixel, next_sample = 0;
     bool more = false, next_idle = false;
     if (pool.dynamic) {
-        // K5: wave ballot + prefix popcount, ONE atomic per wave on the global work counter
-        const unsigned long long mask = __ballot(alive && finished);
-        if (mask) {
-            const int leader = __ffsll((long long)mask) - 1;
+        // K5: wave ballot + prefix popcount, ONE atomic per wave on the wave's shard of the work counter. When the
+        // shard has run dry the wave looks at all shards at once (lane i reads shard i) and moves on to the next one
+        // that still has items — without this, slots died while other shards still held work and the frame ended
+        // on a long, thin tail.
+        unsigned long long need = __ballot(alive && finished);
+        while (need) {
+            const int leader = __ffsll((long long)need) - 1;
+            const bool asking = (need >> lane) & 1ull;
             unsigned long long base = 0;
-            const uint32_t shard = blockIdx.x % WORK_SHARDS;
-            if (lane == leader) base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(mask));
+            if (lane == leader) base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(need));
             base = __shfl(base, leader);
-            if (alive && finished) {
-                const unsigned long long w = shard_item(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)), shard);
+            if (asking) {
+                const unsigned long long w = shard_item(base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull)), shard);
                 if (w < pool.total_work) {
                     more = true;
                     next_idle = !work_to_pixel(pool, w, next_pixel, next_sample);
                 }
+            }
+            need = __ballot(asking && !more);
+            if (need) {
+                static_assert(WORK_SHARDS == 64, "one lane per shard");
+                const unsigned long long live = __ballot(shard_item(cnt->work[lane].next, (uint32_t)lane) < pool.total_work);
+                if (live == 0ull) break;                                       // the frame's sample budget is handed out
+                const unsigned long long above = live & ~((2ull << shard) - 1ull);   // next live shard after this one, cyclically
+                shard = (uint32_t)(__ffsll((long long)(above ? above : live)) - 1);
             }
         }
     } else if (alive && finished) {
@@ -732,11 +743,12 @@ template <bool SORT, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     unsigned long long n_done = 0, n_died = 0;
     const int lane = (int)(threadIdx.x & 63u);
+    uint32_t shard = blockIdx.x % WORK_SHARDS;   // work-counter shard this wave draws from (wave-uniform; moves on when it runs dry)
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_extend = 0;
     if (!SORT) {
         // n_alloc is a multiple of 256: whole waves run every chunk (wave ballots inside shade_slot)
         for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK)
-            shade_slot(sc, cam, pool, cnt, seed, base + threadIdx.x, lane, true, n_done, n_died);
+            shade_slot(sc, cam, pool, cnt, seed, base + threadIdx.x, lane, true, shard, n_done, n_died);
     } else {
         __shared__ uint16_t s_perm[SORT_WINDOW];
         constexpr uint32_t NCLASS = 3u + MAT_KINDS, K_IDLE = 1u + MAT_KINDS, K_DEAD = 2u + MAT_KINDS;   // miss, one per material kind, idle, dead
@@ -811,7 +823,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
                 if (g * 64u >= n_live) break;
                 // lanes past n_live in the last group are bystanders
-                shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[g * 64u + lane], lane, g * 64u + (uint32_t)lane < n_live, n_done, n_died);
+                shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[g * 64u + lane], lane, g * 64u + (uint32_t)lane < n_live, shard, n_done, n_died);
             }
             __syncthreads();   // LDS is reused by the next window
         }

@@ -206,7 +206,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const uint64_t total_work = dynamic ? n_tile_pixels64 * spp : (uint64_t)n_pixels * spp;
     uint64_t n_slots64;
     if (dynamic) {
-        uint64_t target = (uint64_t)ctx->n_cus * 16384ull;   // ~4M resident paths on 256 CUs
+        uint64_t target = (uint64_t)ctx->n_cus * 65536ull;   // ~16.8M resident paths on 256 CUs (2.5 GB of path state): per-launch fixed costs and
+                                                              // kernel tails amortise over 4x more segments than at 4M (+9% measured); 32M is level, 64M slower
         if (const char* e = getenv("PT_POOL_SLOTS")) target = strtoull(e, nullptr, 10);
         n_slots64 = std::min<uint64_t>(target, std::max<uint64_t>(total_work, 1));
     } else {

@@ -29,7 +29,7 @@ for k, cs in vals.items():
         o[c] = {"mean": sum(v) / len(v), "first": v[0], "max": max(v), "n": len(v)}
     out[k] = o
 # calibration of the byte counters on launches with known traffic (dynamic mode, 4,194,304 slots)
-slots = 4194304
+slots = int(sys.argv[3]) if len(sys.argv) > 3 else 16777216   # resident paths of the profiled run (256 CUs x 65536)
 cal = {}
 if "k_init" in out and "WRITE_SIZE" in out["k_init"]:
     known = slots * (64 + 64 + 8 + 4 + 4)                 # k_init writes RayRec + PathRec + hit_t + hit_prim + bounce per slot
