@@ -764,9 +764,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             if (s_win >= n_windows) break;
             const uint32_t wbase = s_win * SORT_WINDOW;
             // classify; STABLE counting sort (slot order is kept inside a class, so the work items a
-            // wave dequeues — consecutive pixels of one tile — land in neighbouring slots and the next
-            // k_extend sees coherent primary rays)
-            uint32_t keys = 0, ranks = 0;   // 8 x 4-bit class keys, 8 x ... ranks kept separately below
+            // wave dequeues — consecutive pixels of one tile — stay together in a group). The material
+            // kind travels in PrimRef::kind (bits 16..23): one dependent load after hit_prim, not two.
+            uint32_t keys = 0;   // 8 x 4-bit class keys
             uint32_t rank[PER];
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -777,18 +777,22 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 else if (b0 == SLOT_IDLE) key = K_IDLE;
                 else {
                     const uint32_t g0 = pool.hit_prim[s0];
-                    key = g0 == HIT_NONE ? 0u : 1u + sc.mats[sc.prims[g0].mat].kind;
+                    key = g0 == HIT_NONE ? 0u : 1u + ((sc.prims[g0].kind >> PRIM_MAT_KIND_SHIFT) & 0xFFu);
                 }
                 keys |= key << (4 * j);
                 rank[j] = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < NCLASS; ++k) {
+                for (uint32_t k = 0; k < NCLASS; ++k)
+                    if (lane == 0) s_cnt[k][j * (BLOCK / 64) + wave] = 0;
+                // only the classes present among the wave's 64 slots cost a ballot (typically two to four)
+                unsigned long long todo = ~0ull;
+                while (todo) {
+                    const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)key, __ffsll((long long)todo) - 1));
                     const unsigned long long m = __ballot(key == k);
                     if (key == k) rank[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (lane == 0) s_cnt[k][j * (BLOCK / 64) + wave] = (uint32_t)__popcll(m);
+                    todo &= ~m;
                 }
             }
-            (void)ranks;
             __syncthreads();
             if (threadIdx.x < NCLASS) {   // one thread per class: exclusive prefix over the groups in slot order
                 uint32_t acc = 0;
@@ -822,8 +826,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 if (lane == 0) g = atomicAdd(&s_next, 1u);
                 g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
                 if (g * 64u >= n_live) break;
-                // lanes past n_live in the last group are bystanders
-                shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[g * 64u + lane], lane, g * 64u + (uint32_t)lane < n_live, shard, n_done, n_died);
+                // groups are taken from the END of the sorted order: the expensive classes (principled, glass) sort
+                // last, and starting with them keeps the four waves level when the window runs out (the cheap
+                // misses fill the gaps). Lanes past n_live in the top group are bystanders.
+                const uint32_t q = ((n_live + 63u) / 64u - 1u - g) * 64u + (uint32_t)lane;
+                shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[q < n_live ? q : 0u], lane, q < n_live, shard, n_done, n_died);
             }
             __syncthreads();   // LDS is reused by the next window
         }

@@ -206,8 +206,12 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const uint64_t total_work = dynamic ? n_tile_pixels64 * spp : (uint64_t)n_pixels * spp;
     uint64_t n_slots64;
     if (dynamic) {
-        uint64_t target = (uint64_t)ctx->n_cus * 65536ull;   // ~16.8M resident paths on 256 CUs (2.5 GB of path state): per-launch fixed costs and
-                                                              // kernel tails amortise over 4x more segments than at 4M (+9% measured); 32M is level, 64M slower
+        // Resident paths: enough that per-launch fixed costs and kernel tails amortise (16.8M slots are 9% faster than
+        // 4.2M on the 4000-spp frame, 33.6M another 2%), few enough that the frame's end — when the sample budget is
+        // handed out and slots die — stays short: about 128 samples per slot, between 16K and 128K slots per CU
+        // (2.5 GB of path state at 16.8M).
+        const uint64_t per_cu = std::min<uint64_t>(131072, std::max<uint64_t>(16384, total_work / 128 / std::max(1, ctx->n_cus)));
+        uint64_t target = (uint64_t)ctx->n_cus * (per_cu & ~(uint64_t)2047);
         if (const char* e = getenv("PT_POOL_SLOTS")) target = strtoull(e, nullptr, 10);
         n_slots64 = std::min<uint64_t>(target, std::max<uint64_t>(total_work, 1));
     } else {

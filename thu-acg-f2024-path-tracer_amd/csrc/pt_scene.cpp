@@ -564,6 +564,7 @@ int pt::scene_build(pt_scene* s) {
         tlas_items.push_back(BuildItem{world, world.centroid(), (uint32_t)entries.size()});
         entries.push_back(e);
     }
+    for (PrimRef& pr : prims) pr.kind |= (uint32_t)s->mats[pr.mat].kind << PRIM_MAT_KIND_SHIFT;
     std::vector<Box> entry_boxes(tlas_items.size());
     for (const BuildItem& it : tlas_items) entry_boxes[it.ref_payload] = it.box;
     // Build the TLAS over world entries (one entry per leaf).

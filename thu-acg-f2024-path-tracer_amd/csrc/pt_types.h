@@ -36,6 +36,7 @@ constexpr int MAX_TLAS_DEPTH = 10;
 enum PrimKind : uint32_t { PRIM_SPHERE = 0, PRIM_QUAD = 1, PRIM_TRI = 2 };
 enum EntryKind : uint32_t { ENTRY_SPHERE = 0, ENTRY_QUAD = 1, ENTRY_CUBOID = 2, ENTRY_MESH = 3 };
 constexpr uint32_t PRIM_HAS_NORMALS = 1u << 8, PRIM_HAS_UVS = 1u << 9;
+constexpr uint32_t PRIM_MAT_KIND_SHIFT = 16;   // PrimRef::kind bits 16..23: MatKind of the primitive's material (k_shade's class sort)
 
 struct PrimRef {         // indexed by GLOBAL primitive id (lights list first, then objects)
     uint32_t kind;       // PrimKind | PRIM_HAS_*
