@@ -185,6 +185,43 @@ def test_slot_layouts_and_sample_ranges_agree(pt, det, ctx):
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+def test_kernel_forms_and_pool_sizes_agree(pt, ctx):
+    """Every K2 form (two-phase with flat / tree top level, batch, dynamic fetch), the K3 forms and small path
+    pools (work-counter shards run dry and are stolen from) give the same accumulator: bit for bit with
+    slots_per_pixel=1, up to f64 summation order in the dynamic mode."""
+    def render(k, spp):
+        gs = pt.Scene(ctx)
+        cam = gs.build_scene(6, 96, spp)                             # the scene build reads PT_NO_FLAT_TLAS
+        acc, st = gs.render(cam, 4, 0, spp, slots_per_pixel=k)
+        gs.close()
+        return acc, st
+    ref, st0 = render(1, 6)
+    assert st0.extend_variant == 0                                   # two-phase kernel is the default with meshes
+    for env in ({"PT_NO_FLAT_TLAS": "1"}, {"PT_FETCH_THRESHOLD": "-1"}, {"PT_FETCH_THRESHOLD": "16"}, {"PT_EXT2": "243"},
+                {"PT_SHADE_VARIANT": "2"}, {"PT_SHADE_VARIANT": "13"}):
+        acc, st = _with_env(env, lambda: render(1, 6))
+        np.testing.assert_array_equal(acc, ref, err_msg=str(env))
+        assert st.segments == st0.segments
+    ref40, st40 = render(1, 40)
+    fin = np.isfinite(ref40)
+    for env in ({}, {"PT_POOL_SLOTS": "4096"}, {"PT_POOL_SLOTS": "1000"}, {"PT_POOL_SLOTS": "70000", "PT_NO_FLAT_TLAS": "1"}):
+        acc, st = _with_env(env, lambda: render(0, 40))
+        assert st.samples == 96 * 54 * 40 and st.segments == st40.segments, env
+        np.testing.assert_allclose(acc[fin], ref40[fin], rtol=1e-11, atol=1e-11, err_msg=str(env))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_random_scenes_bit_exact(pt, det, ctx, seed):
     """Fuzz: random spheres / moving spheres / quads / instanced cuboids / instanced meshes with random
     diffuse, metal, glass and principled materials, checker textures, quad (+ sphere) lights."""

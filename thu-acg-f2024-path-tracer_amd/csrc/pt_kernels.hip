@@ -293,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 // ---------------------------------------------------------------------------------------
 // K2, two-phase form (default). The batch kernel above leaves most lanes idle: a sky ray is done
 // after ~5 steps while a lane next to it walks a mesh for 50-150 (17 % VALU lane utilisation in the
-// first profile). Here a block takes a WINDOW of 1024 slots and
+// first profile). Here a block takes a WINDOW of 2048 slots and
 //   phase A: every ray walks only the TOP-LEVEL tree; spheres / quads / cuboids are intersected on
 //            the spot, mesh instances whose box it enters are only RECORDED (<= 4 per ray, in LDS);
 //   phase B: the rays that recorded something are compacted into an LDS list and the block's waves
@@ -306,13 +306,14 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 // The phase-A best hit of a ray waits in LDS (t and id), and the window's final primitive ids leave
 // with ONE coalesced store per slot: k_shade re-intersects the primitive (reconstruct_hit) and never
 // needs t, so 4 B per slot is all this kernel writes.
-// LDS per block: STACK x 1 KB (traversal stacks) + 19 KB, STACK in {16, 20, 24}: the host picks the
+// LDS per block: STACK x 1 KB (traversal stacks) + 18.5 KB, STACK in {16, 20, 24}: the host picks the
 // smallest that covers the scene (pt_scene::stack_need_extend2 — only the deepest mesh tree when the top
 // level is walked flat); deeper scenes use the batch kernel. The kernel runs three blocks per CU: a
 // fourth would cap it at 128 registers and the spills cost more than the extra waves bring (measured).
 // Tried and dropped: the two phases as two kernels with a global candidate list; every
 // wave on its own 256-slot window without block barriers; warming the next window's ray lines.
-constexpr int EXT_WINDOW = 1024, EXT_MAXI = 4;
+constexpr int EXT_WINDOW = 2048;   // slots per block window
+constexpr int EXT_CAND = 768;      // candidate list of a window (LDS); a fuller window walks the rest in phase A
 
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
     RayD r = wray;
@@ -348,18 +349,16 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
 template <int EXT_STACK, int MINB>
 __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
     __shared__ uint32_t stack[EXT_STACK * BLOCK];
-    __shared__ double s_best_t[EXT_WINDOW];                        //  8 KB  phase-A best hit of the rays with recorded meshes
-    __shared__ uint32_t s_best_id[EXT_WINDOW];                     //  4 KB  closest primitive of every slot of the window
-    __shared__ uint8_t s_items[EXT_WINDOW * EXT_MAXI];             //  4 KB  recorded mesh entries per ray
-    __shared__ uint8_t s_nitems[EXT_WINDOW];
-    __shared__ uint16_t s_rays[EXT_WINDOW];                        // rays with recorded meshes
-    __shared__ uint32_t s_nrays, s_next;
+    __shared__ uint32_t s_best_id[EXT_WINDOW];                     //  8 KB  closest primitive of every slot of the window
+    __shared__ double s_cand_t[EXT_CAND];                          //  6 KB  candidates (rays that entered mesh boxes): phase-A best t,
+    __shared__ uint32_t s_cand_items[EXT_CAND];                    //  3 KB  recorded mesh entries, 8 bit each, 0xFF = none,
+    __shared__ uint16_t s_cand_sl[EXT_CAND];                       //        slot inside the window
+    __shared__ uint32_t s_nrays, s_next, s_win;
     uint32_t* stk = &stack[threadIdx.x];
     const int lane = (int)(threadIdx.x & 63u);
     const double t_min = 1e-3;                                     // camera.rs:171,179
     const float t_min_f = __double2float_rd(t_min);
     unsigned long long nseg = 0;
-    __shared__ uint32_t s_win;
     const uint32_t n_windows = pool.n_alloc / EXT_WINDOW;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
     for (;;) {
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         __syncthreads();
         if (s_win >= n_windows) break;
         const uint32_t wbase = s_win * EXT_WINDOW;
-        // ---- phase A: top-level tree only --------------------------------------------------------
+        // ---- phase A: top level only ---------------------------------------------------------------
         // the ray of the NEXT chunk is requested before this chunk's traversal starts: with three waves per
         // SIMD nothing else hides the 2-3 us an HBM fetch takes
         bool alive_next = pool.bounce[wbase + threadIdx.x] < SLOT_IDLE;
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 alive_next = pool.bounce[wbase + sl + BLOCK] < SLOT_IDLE;
                 if (alive_next) r_next = load_ray(pool, wbase + sl + BLOCK);
             }
-            uint32_t n_my = 0;
+            uint32_t n_my = 0, items = 0xFFFFFFFFu;
             RayF f{};
             Closest best{D_INF, HIT_NONE};
             float t_max_f = t_max_f32(best.t);
@@ -392,10 +391,11 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
             // one world entry whose box the ray enters: meshes are recorded, everything else is tested on the spot
             auto visit_entry = [&](uint32_t ei, const Entry& e, int sp) {
                 if (e.kind == ENTRY_MESH) {
-                    if (n_my < (uint32_t)EXT_MAXI && ei <= 0xFFu) {
-                        s_items[sl * EXT_MAXI + n_my++] = (uint8_t)ei;            // defer to phase B
+                    if (n_my < 4u && ei < 0xFFu) {
+                        items = (items & ~(0xFFu << (8u * n_my))) | (ei << (8u * n_my));   // defer to phase B
+                        ++n_my;
                     } else {
-                        blas_pass(sc, r, e, t_min, t_min_f, stk + (size_t)sp * BLOCK, EXT_STACK - sp, best);   // overflow: walk it now
+                        blas_pass(sc, r, e, t_min, t_min_f, stk + (size_t)sp * BLOCK, EXT_STACK - sp, best);   // a fifth mesh / a wide index: walk it now
                         t_max_f = t_max_f32(best.t);
                     }
                 } else {
@@ -438,25 +438,30 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                     cur = stk[(--sp) * BLOCK];
                 }
             }
-            const uint32_t id_a = alive ? best.id : HIT_NONE;
-            if (n_my > 0) {   // phase-A best waits in LDS for phase B
-                s_best_t[sl] = best.t;
-                s_nitems[sl] = (uint8_t)n_my;
-            }
-            s_best_id[sl] = id_a;
-            // compact the rays that recorded meshes (slot order inside a wave is kept)
+            // append the rays that recorded meshes to the window's candidate list (one LDS atomic per wave, slot
+            // order kept inside the wave); when the list is full — a window that is nearly all mesh — walk them now
             const unsigned long long m = __ballot(n_my > 0);
             if (m) {
                 const int leader = __ffsll((long long)m) - 1;
                 uint32_t base = 0;
                 if (lane == leader) base = atomicAdd(&s_nrays, (uint32_t)__popcll(m));
                 base = (uint32_t)__shfl((int)base, leader);
-                if (n_my > 0) s_rays[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)sl;
+                if (n_my > 0) {
+                    const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < (uint32_t)EXT_CAND) {
+                        s_cand_t[pos] = best.t;
+                        s_cand_items[pos] = items;
+                        s_cand_sl[pos] = (uint16_t)sl;
+                    } else {
+                        for (uint32_t k = 0; k < n_my; ++k) blas_pass(sc, r, sc.entries[(items >> (8u * k)) & 0xFFu], t_min, t_min_f, stk, EXT_STACK, best);
+                    }
+                }
             }
+            s_best_id[sl] = alive ? best.id : HIT_NONE;
         }
         __syncthreads();
         // ---- phase B: mesh traversals, 64 rays per pull ------------------------------------------------
-        const uint32_t n_rays = s_nrays;
+        const uint32_t n_rays = s_nrays < (uint32_t)EXT_CAND ? s_nrays : (uint32_t)EXT_CAND;
         for (;;) {
             uint32_t g = 0;
             if (lane == 0) g = atomicAdd(&s_next, 1u);
@@ -464,13 +469,14 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
             if (g * 64u >= n_rays) break;
             const uint32_t idx = g * 64u + (uint32_t)lane;
             if (idx < n_rays) {
-                const uint32_t sl = s_rays[idx], slot = wbase + sl;
+                const uint32_t sl = s_cand_sl[idx], slot = wbase + sl;
                 const RayD r = load_ray(pool, slot);
-                Closest best{s_best_t[sl], s_best_id[sl]};
-                const uint32_t n_my = s_nitems[sl];
-                for (uint32_t k = 0; k < n_my; ++k) {
-                    const Entry e = sc.entries[s_items[sl * EXT_MAXI + k]];
-                    blas_pass(sc, r, e, t_min, t_min_f, stk, EXT_STACK, best);
+                Closest best{s_cand_t[idx], s_best_id[sl]};
+                const uint32_t items = s_cand_items[idx];
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t ei = (items >> (8u * k)) & 0xFFu;
+                    if (ei == 0xFFu) break;
+                    blas_pass(sc, r, sc.entries[ei], t_min, t_min_f, stk, EXT_STACK, best);
                 }
                 s_best_id[sl] = best.id;
             }

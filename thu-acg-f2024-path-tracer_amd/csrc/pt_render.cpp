@@ -210,8 +210,9 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         // 4.2M on the 4000-spp frame, 33.6M another 2%), few enough that the frame's end — when the sample budget is
         // handed out and slots die — stays short: about 128 samples per slot, between 16K and 128K slots per CU
         // (2.5 GB of path state at 16.8M).
-        const uint64_t per_cu = std::min<uint64_t>(131072, std::max<uint64_t>(16384, total_work / 128 / std::max(1, ctx->n_cus)));
-        uint64_t target = (uint64_t)ctx->n_cus * (per_cu & ~(uint64_t)2047);
+        uint64_t per_cu = 16384;   // a power of two (the tile-ordered work items and the 64 counter shards divide it evenly)
+        while (per_cu < 131072 && per_cu * 3 / 2 * (uint64_t)std::max(1, ctx->n_cus) * 128 <= total_work) per_cu *= 2;
+        uint64_t target = (uint64_t)ctx->n_cus * per_cu;
         if (const char* e = getenv("PT_POOL_SLOTS")) target = strtoull(e, nullptr, 10);
         n_slots64 = std::min<uint64_t>(target, std::max<uint64_t>(total_work, 1));
     } else {
