@@ -32,7 +32,7 @@ for k, cs in vals.items():
 slots = int(sys.argv[3]) if len(sys.argv) > 3 else 16777216   # resident paths of the profiled run (256 CUs x 65536)
 cal = {}
 if "k_init" in out and "WRITE_SIZE" in out["k_init"]:
-    known = slots * (64 + 64 + 8 + 4 + 4)                 # k_init writes RayRec + PathRec + hit_t + hit_prim + bounce per slot
+    known = slots * (64 + 32 + 4 + 4)                     # k_init (dynamic mode) writes RayRec + PathRec + hit_prim + bounce per slot
     cal["write_factor"] = known / (out["k_init"]["WRITE_SIZE"]["first"] * 1024)
 if "k_extend" in out and "FETCH_SIZE" in out["k_extend"]:
     known = slots * (64 + 4)                              # first k_extend launch: every slot alive, RayRec + bounce
