@@ -2,9 +2,14 @@
  * C API of the CPU restatement (f64) of the reference's integrator path
  * (camera.rs, hittable/, bsdf/ of chiefchewie/thu-acg-f2024-path-tracer).
  * Parity status: the reference is Rust and cannot be built here (no cargo/rustc), it has
- * no tests or golden vectors, and its RNG is unseedable — so this oracle is pinned by
- * hand-derived known-answer values (a2, a18, a19, a20, a24), Philox known-answer
- * vectors and identities only. Against the Rust binary itself: "parity unpinned".
+ * no tests or golden vectors, and its RNG is unseedable — so no bit-level golden exists
+ * ("parity unpinned" at that level). What pins this oracle: hand-derived known-answer values
+ * (a2, a18, a19, a20, a24), Philox known-answer vectors, identities, an independent
+ * numpy brute force for the BVH, and — statistically — the reference's OWN rendered outputs:
+ * demo/{earth,lights,bsdf,scene6,balls}.png as 48x27 block means (tests/golden/
+ * reference_demo_blocks.npz): block correlation 0.994-1.0, mean |diff| <= 0.012 in gamma space
+ * for scenes 2, 4, 5, 6 (scene 6 without the "spot" mesh, which that image shows with an older
+ * material — see tests/common.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library. The builder calls mirror include/pt_amd.h one-to-one so that one scene

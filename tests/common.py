@@ -146,3 +146,30 @@ def random_scene(seed, with_mesh=True, with_lights=True, n_objects=10, sphere_li
     s.add("world_build")
     s.camera = default_camera(env_color=(0.6, 0.7, 0.9) if not with_lights else (0.05, 0.05, 0.08))
     return s
+
+
+# ---- the reference's own rendered outputs (demo/*.png) as coarse fixtures ---------------------------
+# tests/golden/reference_demo_blocks.npz (tools/make_demo_fixture.py): 48x27 block means of the gamma-space
+# 1920x1080 images the reference repository ships for its scene scripts 1, 2, 4, 5, 6 (unknown seed; the
+# reference's RNG cannot be seeded). Scene 6: the blocks covering the "spot" mesh are left out — in that
+# image spot is smooth-shaded, bright and translucent-looking, which the code of the mounted commit cannot
+# produce from assets/spot.obj (no normals: the cow next to it, same loader, is faceted in the same image),
+# so that object was rendered with an older material/loader; everything else in the frame agrees.
+DEMO_TOL = {2: (0.02, 0.995), 4: (0.01, 0.999), 5: (0.025, 0.99), 6: (0.025, 0.985)}   # scene -> (max mean-abs-diff, min correlation)
+
+
+def demo_block_stats(scene_id, rgb8):
+    """(mean absolute difference per channel, correlation per channel) between the 48x27 block means of an
+    RGB8 render of `scene_id` (any size that is a multiple of 48x27) and the reference's demo image."""
+    import os
+    ref = np.load(os.path.join(GOLDEN_DIR, "reference_demo_blocks.npz"))[f"scene{scene_id}"].astype(np.float64)
+    img = np.asarray(rgb8, dtype=np.float64) / 255.0
+    h, w, _ = img.shape
+    assert h % 27 == 0 and w % 48 == 0, (h, w)
+    blocks = img.reshape(27, h // 27, 48, w // 48, 3).mean(axis=(1, 3))
+    keep = np.ones((27, 48), dtype=bool)
+    if scene_id == 6:
+        keep[1:13, 27:36] = False
+    d = np.abs(blocks - ref)[keep]
+    corr = np.array([np.corrcoef(blocks[..., c][keep], ref[..., c][keep])[0, 1] for c in range(3)])
+    return d.mean(axis=0), corr, blocks.mean(axis=(0, 1)), ref.mean(axis=(0, 1))

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from common import GOLDEN_DIR, SceneSpec, default_camera, icosphere, random_scene
+from common import DEMO_TOL, GOLDEN_DIR, SceneSpec, default_camera, demo_block_stats, icosphere, random_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -184,7 +184,18 @@ def test_slot_layouts_and_sample_ranges_agree(pt, det, ctx):
     gs.close()
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("sid", [2, 4, 5, 6])
+def test_product_matches_reference_demo_images(pt, ctx, sid):
+    """The HIP path against the reference's own rendered outputs (demo/*.png as 48x27 block means, see
+    common.demo_block_stats): 480x270 @ 256 spp in the default dynamic mode."""
+    gs = pt.Scene(ctx)
+    cam = gs.build_scene(sid, 480, 256)
+    acc, _ = gs.render(cam, 1, 0, 256)
+    mad, corr, _, _ = demo_block_stats(sid, ctx.resolve_u8(acc, 256))
+    assert (mad < DEMO_TOL[sid][0]).all() and (corr > DEMO_TOL[sid][1]).all(), (mad, corr)
+    gs.close()
+
+
 def _with_env(env, fn):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
