@@ -219,7 +219,8 @@ def test_kernel_forms_and_pool_sizes_agree(pt, ctx):
         return acc, st
     ref, st0 = render(1, 6)
     assert st0.extend_variant == 0                                   # two-phase kernel is the default with meshes
-    for env in ({"PT_NO_FLAT_TLAS": "1"}, {"PT_FETCH_THRESHOLD": "-1"}, {"PT_FETCH_THRESHOLD": "16"}, {"PT_EXT2": "243"},
+    for env in ({"PT_NO_FLAT_TLAS": "1"}, {"PT_FETCH_THRESHOLD": "-1"}, {"PT_FETCH_THRESHOLD": "-1", "PT_NO_FLAT_TLAS": "1"},
+                {"PT_FETCH_THRESHOLD": "16"}, {"PT_EXT2": "243"},
                 {"PT_SHADE_VARIANT": "2"}, {"PT_SHADE_VARIANT": "13"}):
         acc, st = _with_env(env, lambda: render(1, 6))
         np.testing.assert_array_equal(acc, ref, err_msg=str(env))

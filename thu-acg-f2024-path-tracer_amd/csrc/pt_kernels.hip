@@ -273,19 +273,59 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
     }
 }
 
+PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best);
+
+// Closest hit with the top level walked FLAT (SceneD::tlas_flat: at most TLAS_FLAT_MAX world entries): the
+// wave loops over the entry list together — the entry index is wave-uniform, so boxes, entries and instance
+// transforms arrive by scalar loads, there is no top-level stack, and an entry no lane's ray enters costs one
+// f32 box test. Must be called by whole waves (`alive` = false for lanes without a ray).
+PT_DEV Closest closest_hit_flat(const SceneD& sc, bool alive, const RayD& r, double t_min, uint32_t* stk) {
+    Closest best{D_INF, HIT_NONE};
+    const float t_min_f = __double2float_rd(t_min);
+    float t_max_f = t_max_f32(best.t);
+    const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
+    for (uint32_t ei = 0; ei < sc.n_entries; ++ei) {
+        const float* bx = sc.entry_box + 6u * ei;
+        float tn;
+        const bool hb = alive && slab_f32(bx, bx + 3, f, t_min_f, t_max_f, tn);
+        if (__ballot(hb) == 0ull) continue;
+        const Entry e = sc.entries[ei];
+        if (hb) {
+            if (e.kind == ENTRY_MESH) {
+                blas_pass(sc, r, e, t_min, t_min_f, stk, TRAVERSAL_STACK, best);
+            } else {
+                RayD lr = r;
+                if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
+                const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
+                for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+            }
+            t_max_f = t_max_f32(best.t);
+        }
+    }
+    return best;
+}
+
 // K2, batch form: a fixed grid walks the pool with a grid-stride loop; each lane traverses one ray
 // at a time, a wave moves on when its slowest lane is done. Lowest overhead; SIMD utilisation
-// suffers when traversal lengths inside a wave differ a lot (sky ray next to a mesh ray).
+// suffers when traversal lengths inside a wave differ a lot (sky ray next to a mesh ray). Used for
+// scenes without meshes (and as the fallback for BVHs deeper than k_extend2's LDS stack).
+template <bool FLAT>   // FLAT: SceneD::tlas_flat (two instantiations so that each keeps its own register budget)
 __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     unsigned long long nseg = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
+    // n_alloc is a multiple of BLOCK: whole waves run every chunk (closest_hit_flat ballots)
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
-        if (pool.bounce[s] >= SLOT_IDLE) continue;
-        RayD r = load_ray(pool, s);
-        Closest c = closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
-        stnt(&pool.hit_prim[s], (uint32_t)(c.id));
-        ++nseg;
+        const bool alive = pool.bounce[s] < SLOT_IDLE;
+        RayD r{};
+        if (alive) r = load_ray(pool, s);
+        Closest c{D_INF, HIT_NONE};
+        if (FLAT) c = closest_hit_flat(sc, alive, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
+        else if (alive) c = closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]);
+        if (alive) {
+            stnt(&pool.hit_prim[s], (uint32_t)(c.id));
+            ++nseg;
+        }
     }
     if (nseg) atomicAdd(&cnt->segments, nseg);
 }
@@ -941,7 +981,7 @@ static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min 
 }
 void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int fetch_threshold, hipStream_t st) {
     if (fetch_threshold <= -100) hipLaunchKernelGGL(pick_extend2(-fetch_threshold), grid_for((pool.n_alloc / EXT_WINDOW) * BLOCK, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
-    else if (fetch_threshold < 0) hipLaunchKernelGGL(k_extend, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    else if (fetch_threshold < 0) hipLaunchKernelGGL(sc.tlas_flat ? k_extend<true> : k_extend<false>, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
     else hipLaunchKernelGGL(k_extend_fetch, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt, fetch_threshold);
 }
 typedef void (*shade_fn)(SceneD, CamD, PoolD, CountersD*, uint64_t);
@@ -973,7 +1013,7 @@ void launch_math_probe(int which, const double* in, uint32_t n, double* out, hip
 }
 int kernel_occupancy_blocks(int which, int variant) {
     int nb = 0;
-    const void* f = which == 0 ? (variant > 0 ? (const void*)k_extend_fetch : variant <= -100 ? (const void*)pick_extend2(-variant) : (const void*)k_extend) : (const void*)pick_shade(variant);
+    const void* f = which == 0 ? (variant > 0 ? (const void*)k_extend_fetch : variant <= -100 ? (const void*)pick_extend2(-variant) : variant == -2 ? (const void*)k_extend<true> : (const void*)k_extend<false>) : (const void*)pick_shade(variant);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

@@ -223,7 +223,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     }
     if (n_slots64 > 0x7FFFFFC0ull) return set_error("pt_render: image too large for the path pool");
     const uint32_t n_slots = (uint32_t)n_slots64;
-    // one allocation, carved into the SoA arrays (17 f64 + 5 u32 per slot)
+    // one allocation: the two record arrays (RayRec, PathRec), the static mode's f64 arrays, the two u32 state arrays
     const size_t n_al = ((size_t)n_slots + 2047) & ~(size_t)2047;   // whole 2048-slot windows (k_shade sorts per window)
     const size_t bytes = n_al * (sizeof(RayRec) + sizeof(PathRec) + 6 * sizeof(double) + 2 * sizeof(uint32_t));
     if (bytes > s->pool_bytes) {
@@ -294,7 +294,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         const int v = std::min(64, std::max(-1, atoi(e)));
         fetch_threshold = v == 0 ? (extend2_code() != 0 ? -extend2_code() : -1) : v;
     }
-    const int blocks_extend = kernel_occupancy_blocks(0, fetch_threshold), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
+    const int blocks_extend = kernel_occupancy_blocks(0, fetch_threshold == -1 && s->dev.view.tlas_flat ? -2 : fetch_threshold), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;

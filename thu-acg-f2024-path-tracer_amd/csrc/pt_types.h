@@ -1,6 +1,6 @@
 // Flattened scene + path-pool layout shared by the host scene builder and the HIP kernels.
-// Everything the kernels read lives in HBM as plain arrays of these PODs (SoA for the
-// per-path state, AoS for the small read-only scene tables that sit in L2).
+// Everything the kernels read lives in HBM as plain arrays of these PODs (records for the per-path
+// state and for the small read-only scene tables that sit in L2).
 #pragma once
 #include <stdint.h>
 
@@ -110,11 +110,11 @@ struct SceneD {
     float tlas_extent;           // max |coordinate| of the top-level BVH boxes
     uint32_t n_entries, n_prims, n_lights;
     const float* entry_box;      // lo[3], hi[3] per entry: its world-space box, padded and rounded outward like the node boxes
-    uint32_t tlas_flat;          // n_entries <= TLAS_FLAT_MAX: k_extend2 walks the entry list instead of the top-level tree
+    uint32_t tlas_flat;          // n_entries <= TLAS_FLAT_MAX: K2 walks the entry list instead of the top-level tree
 };
-constexpr uint32_t TLAS_FLAT_MAX = 32;
+constexpr uint32_t TLAS_FLAT_MAX = 12;   // measured: 8-10 entries (Cornell, scene 6) -26 % / -7 % K2 time, 17 entries (scene 5) +20 %
 
-// ---- path pool (SoA, one slot per resident path) ---------------------------------------
+// ---- path pool (one slot per resident path) --------------------------------------------
 // Two work-assignment modes:
 //  static  (slots_per_pixel = k >= 1): slot s owns pixel (s % n_pixels) and renders samples
 //          spp_begin + (s / n_pixels) + j*k into its own accumulator ax/ay/az; deterministic, and
