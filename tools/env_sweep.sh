@@ -1,5 +1,5 @@
 #!/bin/bash
-# experiment sweep over full env assignments: SPEC=6,1920,200 tools/dbg_sweep2.sh "A=1 B=2" "A=2" ... (perf probe per set)
+# experiment sweep over full env assignments: SPEC=6,1920,200 tools/env_sweep.sh "A=1 B=2" "A=2" ... (perf probe per set)
 SPEC=${SPEC:-6,1920,200}
 for v in "$@"; do
   echo "== $v"
