@@ -184,6 +184,38 @@ def test_slot_layouts_and_sample_ranges_agree(pt, det, ctx):
     gs.close()
 
 
+@pytest.mark.parametrize("n_meshes,flat", [(7, True), (20, False)])
+def test_mesh_crowd_bit_exact(pt, det, ctx, n_meshes, flat):
+    """K2's rarely taken paths: a frame filled by overlapping mesh instances — rays that enter more than four
+    mesh boxes (the fifth is walked on the spot), windows whose candidate list (768) overflows, and, with 20
+    world entries, the per-lane walk of the top-level TREE instead of the flat entry list."""
+    rng = np.random.default_rng(42 + n_meshes)
+    spec = SceneSpec()
+    P, I = icosphere(1)
+    mats = [spec.add("mat_diffuse", spec.add("tex_solid_rgb", *rng.uniform(0.2, 0.9, 3)), -1),
+            spec.add("mat_metal", spec.add("tex_solid_rgb", 0.9, 0.8, 0.7), spec.add("tex_solid_f", 0.15)),
+            spec.add("mat_glass", spec.add("tex_solid_rgb", 1.0, 1.0, 1.0), spec.add("tex_solid_f", 0.05), 0.0, 1.5)]
+    for i in range(n_meshes):
+        mesh = spec.add("mesh", float(rng.uniform(0.9, 1.6)), P, I, None, None, mats[i % 3])
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        spec.add("world_add_object", spec.add("instance", mesh, tuple(axis), float(rng.uniform(0, 3)), tuple(rng.uniform(-0.8, 0.8, 3) + (0.0, 0.5, 0.0))))
+    spec.add("world_add_light", spec.add("quad", (-1.0, 4.0, -1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0),
+                                         spec.add("mat_light", spec.add("tex_solid_rgb", 8.0, 8.0, 8.0))))
+    spec.add("world_build")
+    spec.camera = default_camera(width=96, look_from=(0.0, 0.5, -4.0), look_at=(0.0, 0.5, 0.0), vfov=40.0)
+    gs, os_ = pt.Scene(ctx), det.Scene()
+    gres, ores = spec.replay(gs), spec.replay(os_)
+    gcam, ocam = spec.make_camera(pt.Camera, gres), spec.make_camera(det.Camera, ores)
+    ga, st = gs.render(gcam, 3, 0, 4, slots_per_pixel=1)
+    oa, cnt = os_.render(ocam, 3, 0, 4)
+    assert st.extend_variant == 0 and st.segments == cnt["segments"]
+    np.testing.assert_array_equal(ga, oa)
+    gd, _ = gs.render(gcam, 3, 0, 4)                     # dynamic mode: same sums up to f64 addition order
+    fin = np.isfinite(oa)
+    np.testing.assert_allclose(gd[fin], oa[fin], rtol=1e-11, atol=1e-11)
+    gs.close(); os_.close()
+
+
 @pytest.mark.parametrize("sid", [2, 4, 5, 6])
 def test_product_matches_reference_demo_images(pt, ctx, sid):
     """The HIP path against the reference's own rendered outputs (demo/*.png as 48x27 block means, see
