@@ -561,6 +561,17 @@ int pt::scene_build(pt_scene* s) {
         }
         e.n_prims = (uint32_t)prims.size() - e.first_prim;
         Box world = inst >= 0 ? xform_box(local, insts[inst]) : local;
+        if (inst >= 0 && o->kind == OBJ_MESH) {
+            // an instanced mesh gets the bounds of its TRANSFORMED VERTICES, not the box of its transformed box
+            // (aabb.rs:50-76 does the latter): a mesh turned by ~50 degrees has a third less box to enter, and
+            // every ray that enters costs a trip through the mesh pass. Any conservative box gives the same
+            // closest hit; store_box pads by 1e-7 relative, far above the rounding of the transform.
+            Box tight;
+            const InstD& m = insts[inst];
+            for (const TriD& t : o->tris)
+                for (const double* v : {t.v0, t.v1, t.v2}) tight.grow(xform_point(d3(m.c0), d3(m.c1), d3(m.c2), d3(m.t), d3(v)));
+            world = tight;
+        }
         tlas_items.push_back(BuildItem{world, world.centroid(), (uint32_t)entries.size()});
         entries.push_back(e);
     }
