@@ -1,13 +1,14 @@
 // Wavefront path-tracing stages for gfx950 (MI355X). One lane = one resident path.
 //
 //   k_init     K1 raygen       camera.rs:153-168  fills the pool with the first sample of every slot
-//   k_extend   K2 closest hit  world.rs:47-62 -> bvh.rs:123-164 -> sphere/quad/mesh/instance.rs
+//   k_extend2  K2 closest hit  world.rs:47-62 -> bvh.rs:123-164 -> sphere/quad/mesh/instance.rs  (two-phase form; k_extend =
+//                              batch form for scenes without meshes, k_extend_fetch = experimental dynamic-fetch form)
 //   k_shade    K3+K4+K1'       camera.rs:177-226 body: miss/env, emission, RR, one-sample MIS,
 //                              BSDF sample+pdf+eval, next ray; finished paths are regenerated in place
 //   k_resolve  K6 (sum part)   camera.rs:106-109: per-pixel sum of the slot accumulators
 //
 // All kernels are persistent-thread style: a fixed grid sized to the machine walks the pool
-// with a grid-stride loop. No MFMA anywhere — this is branchy f64 scalar work bounded by
+// (grid-stride, or windows drawn from a queue). No MFMA anywhere — this is branchy f64 scalar work bounded by
 // VALU issue and L2 latency, with the path pool streaming through HBM once per stage.
 #include <hip/hip_runtime.h>
 
@@ -18,9 +19,9 @@ namespace pt {
 
 constexpr int BLOCK = 256;
 
-// K2 streams the rays in and the hits out once and never re-reads them, while the scene tables
-// (BVH, primitives: a few MB) are re-read by every wave: non-temporal accesses keep the stream from
-// evicting the scene out of the 4 MB-per-XCD L2. (K3 re-reads its window, so it uses plain accesses.)
+// K2 writes its result (one primitive id per slot) once and never re-reads it, while the scene tables
+// (BVH, primitives: a few MB) are re-read by every wave: the result leaves with non-temporal stores.
+// (Non-temporal LOADS of the path records made no measurable difference and are not used.)
 template <class T> PT_DEV T ldnt(const T* p) { return __builtin_nontemporal_load(p); }
 template <class T> PT_DEV void stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
@@ -779,12 +780,11 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
 constexpr int SORT_WINDOW = 2048;   // slots sorted together by k_shade<true, *>
 
 // K3 launcher kernel. SORT = false: blocks walk the pool in 256-slot chunks, lane i shades slot i.
-// SORT = true: a block takes a WINDOW of 2048 slots, counting-sorts their indices by material class
-// in LDS (miss, diffuse, metal, glass, principled, light, idle, dead), then its four waves pull
-// groups of 64 same-class slots from an LDS cursor until the window is done — waves execute one
-// material's code instead of serialising through all of them, the expensive classes are spread over
-// all waves of the block (work stealing), and state accesses stay inside the window's 16 KB-per-array
-// range.
+// SORT = true (default): a block draws a WINDOW of 2048 slots from a queue, counting-sorts their indices
+// by class in LDS (miss, one class per material kind, idle, dead), then its four waves pull groups of 64
+// same-class slots from an LDS cursor until the window is done — waves execute one material's code
+// instead of serialising through all of them, the expensive classes go first and are spread over all
+// waves of the block (work stealing), and every slot's records are moved whole by its own lane.
 template <bool SORT, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     unsigned long long n_done = 0, n_died = 0;
