@@ -22,7 +22,6 @@ constexpr int BLOCK = 256;
 // K2 writes its result (one primitive id per slot) once and never re-reads it, while the scene tables
 // (BVH, primitives: a few MB) are re-read by every wave: the result leaves with non-temporal stores.
 // (Non-temporal LOADS of the path records made no measurable difference and are not used.)
-template <class T> PT_DEV T ldnt(const T* p) { return __builtin_nontemporal_load(p); }
 template <class T> PT_DEV void stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
 // ---- path records (pt_types.h RayRec / PathRec): one lane moves one whole record, 16 B per access ----
