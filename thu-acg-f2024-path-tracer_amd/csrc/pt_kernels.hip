@@ -971,9 +971,7 @@ typedef void (*extend2_fn)(SceneD, PoolD, CountersD*);
 static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min blocks per CU
     switch (code) {
     case 163: return k_extend2<16, 3>;
-    case 164: return k_extend2<16, 4>;
     case 203: return k_extend2<20, 3>;
-    case 204: return k_extend2<20, 4>;
     case 242: return k_extend2<24, 2>;
     default: return k_extend2<24, 3>;
     }
