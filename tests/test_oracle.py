@@ -84,6 +84,75 @@ def test_kat_sheen_clearcoat_mix(orc):   # sheen.rs:32-44, clearcoat.rs:37-60, m
     s.close()
 
 
+def _principled_eval_numpy(par, base, v, l, front=True):
+    """principled.rs:196-258 + :317-366 written out again in numpy for a solid base colour and normal +z (an
+    independent second reading of the Rust text; rotation-invariant quantities only)."""
+    metallic, roughness, subsurface, specular, specular_tint, ior, spec_trans, sheen, sheen_tint, clearcoat, gloss = par
+    base = np.asarray(base, dtype=np.float64)
+    sw = lambda x: min(max(1.0 - x, 0.0), 1.0) ** 5
+    r0 = lambda eta: ((eta - 1) / (eta + 1)) ** 2
+    lum = base @ np.array([0.2126, 0.7152, 0.0722])
+    c_tint = base / lum if lum > 0 else np.ones(3)
+    vl = lambda a, b, t: a * (1 - t) + b * t                      # glam DVec3::lerp
+    fl_ = lambda a, b, t: a + (b - a) * t                          # glam FloatExt::lerp
+    def fd(w, h, ei, eo):                                           # bsdf/mod.rs:77-88
+        c = abs(w @ h); g2 = (eo / ei) ** 2 - 1 + c * c
+        if g2 < 0: return 1.0
+        g = math.sqrt(g2); x = (c * (g + c) - 1) / (c * (g - c) + 1)
+        return 0.5 * (g - c) ** 2 / (g + c) ** 2 * (1 + x * x)
+    def D(h, r):
+        ct = max(h[2], 0.001); a2 = max(r * r, 0.001); den = (a2 - 1) * ct * ct + 1
+        return a2 / (math.pi * den * den)
+    def G1(w, r):
+        a2 = max(r * r, 0.001); c = abs(w[2])
+        return 2 * c / (c + math.sqrt(c * c * (1 - a2) + a2))
+    w = ((1 - metallic) * (1 - spec_trans), 1 - spec_trans * (1 - metallic), spec_trans * (1 - metallic), 0.25 * clearcoat)
+    reflect = l[2] * v[2] > 0
+    ei, eo = (1.0, ior) if front else (ior, 1.0)
+    h = (l + v) / np.linalg.norm(l + v) * np.sign(v[2]) if reflect else -(l * eo + v * ei) / np.linalg.norm(l * eo + v * ei)
+    out = np.zeros(3)
+    if w[0] > 0 and reflect:
+        sheen_term = sheen * vl(np.ones(3), c_tint, sheen_tint) * sw(abs(l @ h))
+        rr = 2 * roughness * (l @ h) ** 2
+        fl, fv = sw(l[2]), sw(v[2])
+        f_retro = rr * (fl + fv + fl * fv * (rr - 1)); f_d = (1 - 0.5 * fl) * (1 - 0.5 * fv)
+        f_ss = fl_(1.0, 0.5 * rr, fl) * fl_(1.0, 0.5 * rr, fv)
+        ss = 1.25 * (f_ss * (1 / (l[2] + v[2]) - 0.5) + 0.5)
+        out += w[0] * (base / math.pi * fl_(f_d + f_retro, ss, subsurface) + sheen_term)
+    if w[1] > 0 and reflect:
+        c0 = vl(specular * r0(ei / eo) * vl(np.ones(3), c_tint, specular_tint), base, metallic)
+        fres = vl(np.ones(3) * fd(v, h, ei, eo), c0 + (1 - c0) * (1 - l @ h) ** 5, metallic)
+        out += w[1] * fres * G1(v, roughness) * G1(l, roughness) * D(h, roughness) / (4 * abs(l[2]) * abs(v[2]))
+    if w[2] > 0:
+        d, g, f = D(h, roughness), G1(v, roughness) * G1(l, roughness), fd(v, h, ei, eo)
+        if reflect: fac = f * g * d / (4 * abs(l[2]) * abs(v[2]))
+        else: fac = abs(((l @ h) * (v @ h)) / (l[2] * v[2])) * (eo * eo) / (ei * (v @ h) + eo * (l @ h)) ** 2 * (1 - f) * g * d
+        out += w[2] * fac
+    if w[3] > 0 and reflect:
+        ag = (1 - gloss) * 0.1 + gloss * 0.001; a2 = ag * ag; c = abs(l @ h)
+        d = (a2 - 1) / (math.pi * (1 + (a2 - 1) * c * c) * math.log2(a2))
+        out += w[3] * abs(l[2]) * ((0.04 + 0.96 * (1 - l @ h) ** 5) * d * G1(v, 0.25) * G1(l, 0.25) / (4 * abs(l[2]) * abs(v[2])))
+    return out * abs(l[2])
+
+
+@pytest.mark.parametrize("base,par", [
+    ((0.65, 0.05, 0.05), [0.01, 0.01, 0.91, 0.01, 0.01, 1.5, 0.01, 0.91, 0.91, 0.91, 0.01]),    # spot, main.rs:436-450
+    ((1.0, 1.0, 1.0), [0.91, 0.01, 0.01, 0.01, 0.91, 1.5, 0.01, 0.91, 0.91, 0.91, 0.01]),        # bunny, main.rs:411-425
+    ((0.25, 0.05, 0.65), [0.01, 0.21, 0.01, 0.01, 0.01, 1.5, 0.99, 0.01, 0.01, 0.01, 0.01])])    # a glass ball of scene 5
+def test_principled_eval_matches_second_transcription(orc, base, par):
+    """PrincipledBSDF::eval for reflection AND transmission directions against an independent numpy reading
+    of principled.rs (this is the material of the one object whose look differs from demo/scene6.png)."""
+    s = orc.Scene()
+    m = s.mat_principled(s.tex_solid_rgb(*base), par)
+    rng = np.random.default_rng(3)
+    for _ in range(400):
+        v = rng.normal(size=3); v[2] = abs(v[2]); v /= np.linalg.norm(v)
+        l = rng.normal(size=3); l /= np.linalg.norm(l)
+        _, f = s.mat_probe(m, (0.0, 0.0, 1.0), v, l)
+        np.testing.assert_allclose(f, _principled_eval_numpy(par, base, v, l), rtol=1e-10, atol=1e-300)
+    s.close()
+
+
 def test_kat_camera_init(orc):   # a2: camera.rs:51-77
     s = orc.Scene()
     cam = s.build_scene(3, 600, 100)
