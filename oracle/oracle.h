@@ -113,6 +113,8 @@ double orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t 
 double orc_probe(int which, const double* args);
 /* pdf (out4[0]) and eval (out4[1..3]) of one material at a synthetic hit with normal n, uv (0.5,0.5) */
 int orc_mat_probe(orc_scene*, int mat, const double* n, const double* wo, const double* wi, double* out4);
+/* n_samples directions from BxDFMaterial::sample at the same synthetic hit: out = n x (dir xyz, 1 Some / 0 None) */
+int orc_mat_sample_probe(orc_scene*, int mat, const double* n, const double* wo, uint64_t seed, uint32_t n_samples, double* out);
 /* primitive-level probe: closest hit of one ray against the built world.
  * out = {hit(0/1), t, prim_id, u, v, front_face, px,py,pz, gnx,gny,gnz, snx,sny,snz} */
 int orc_intersect(orc_scene*, const double origin[3], const double dir[3], double time, double out[15]);

@@ -171,6 +171,25 @@ extern "C" int orc_mat_probe(orc_scene* s, int mat, const double* n, const doubl
     out4[1] = f.x; out4[2] = f.y; out4[3] = f.z;
     return 0;
 }
+// material-level sampling probe: n_samples directions drawn by BxDFMaterial::sample at the same synthetic hit
+// (normal n, uv (0.5, 0.5)) for view direction wo; out = n_samples x 4 (dir xyz, 1 = Some / 0 = None).
+extern "C" int orc_mat_sample_probe(orc_scene* s, int mat, const double* n, const double* wo, uint64_t seed, uint32_t n_samples, double* out) {
+    if (mat < 0 || mat >= (int)s->mats.size()) return -1;
+    HitInfo info{};
+    info.geometric_normal = info.shading_normal = normalize(V3{n[0], n[1], n[2]});
+    info.front_face = true;
+    info.u = info.v = 0.5;
+    info.mat = s->mats[mat].get();
+    V3 v = normalize(V3{wo[0], wo[1], wo[2]});
+    Ray ray{info.geometric_normal, -v, 0.0};   // ray.direction() = -view_dir, as trace() calls sample (camera.rs:207)
+    for (uint32_t i = 0; i < n_samples; ++i) {
+        Rng rng(seed, 0u, i);
+        V3 d{0, 0, 0};
+        bool ok = info.mat->sample(ray, info, rng, d);
+        out[4 * i] = d.x; out[4 * i + 1] = d.y; out[4 * i + 2] = d.z; out[4 * i + 3] = ok ? 1.0 : 0.0;
+    }
+    return 0;
+}
 extern "C" int orc_mat_light(orc_scene* s, int tex) {
     CHECK_TEX_RGB(s, tex);
     auto m = std::make_shared<DiffuseLight>();

@@ -86,6 +86,7 @@ def _load():
     lib.orc_rng_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.orc_rng_uniform.restype = C.c_double
     lib.orc_mat_probe.argtypes = [C.c_void_p, C.c_int, d3, d3, d3, d3]
+    lib.orc_mat_sample_probe.argtypes = [C.c_void_p, C.c_int, d3, d3, C.c_uint64, C.c_uint32, C.c_void_p]
     lib.orc_probe.argtypes = [C.c_int, d3]
     lib.orc_probe.restype = C.c_double
     lib.orc_intersect.argtypes = [C.c_void_p, d3, d3, C.c_double, d3]
@@ -167,6 +168,11 @@ class Scene:
     def mat_mix(self, t, m1, m2): return _check(lib.orc_mat_mix(self.handle, t, m1, m2))
     def mat_sheen(self, rgb, sheen_tint): return _check(lib.orc_mat_sheen(self.handle, rgb[0], rgb[1], rgb[2], sheen_tint))
     def mat_clearcoat(self, gloss): return _check(lib.orc_mat_clearcoat(self.handle, gloss))
+    def mat_sample_probe(self, mat, n, wo, seed, n_samples):
+        out = np.zeros((n_samples, 4), dtype=np.float64)
+        _check(lib.orc_mat_sample_probe(self.handle, mat, _d3(n), _d3(wo), seed, n_samples, out.ctypes.data))
+        return out[:, :3], out[:, 3] > 0
+
     def mat_probe(self, mat, n, wo, wi):
         out = (C.c_double * 4)()
         _check(lib.orc_mat_probe(self.handle, mat, _d3(n), _d3(wo), _d3(wi), out))

@@ -153,6 +153,37 @@ def test_principled_eval_matches_second_transcription(orc, base, par):
     s.close()
 
 
+def test_diffuse_sampler_matches_its_pdf_and_ggx_sampler_does_not(orc):
+    """BxDFMaterial::sample vs BxDFMaterial::pdf: E_sample[h(w)] against the integral of h(w) pdf(w) dw for
+    h = 1, w.z, w.z^2, w.x. The Lambert sampler is consistent with its pdf. The GGX materials of the reference are
+    NOT, and the restatement must not "fix" that: ggx::sample_microfacet_normal stretches the view vector by
+    roughness^2 (sampling.rs:57-58 passes `roughness * roughness` as the VNDF's alpha) while ggx::D and G1 use
+    alpha^2 = roughness^2, i.e. alpha = roughness (sampling.rs:38-55). The mismatch is measured here so that a
+    change of either side shows up."""
+    s = orc.Scene()
+    rgb = s.tex_solid_rgb(0.8, 0.7, 0.6)
+    diffuse, metal = s.mat_diffuse(rgb, -1), s.mat_metal(rgb, s.tex_solid_f(0.35))
+    n = (0.0, 0.0, 1.0)
+    v = np.array([0.5, -0.2, 0.7]); v /= np.linalg.norm(v)
+    nz, nphi = 200, 360                                   # midpoint rule in cos(theta), phi over the upper hemisphere
+    z = (np.arange(nz) + 0.5) / nz
+    phi = (np.arange(nphi) + 0.5) * (2 * math.pi / nphi)
+    Z, PHI = np.meshgrid(z, phi, indexing="ij")
+    R = np.sqrt(1 - Z * Z)
+    dirs = np.stack([R * np.cos(PHI), R * np.sin(PHI), Z], axis=-1).reshape(-1, 3)
+    dw = (1 / nz) * (2 * math.pi / nphi)
+    tests = [lambda w: np.ones(len(w)), lambda w: w[:, 2], lambda w: w[:, 2] ** 2, lambda w: w[:, 0]]
+    gaps = {}
+    for name, m in (("diffuse", diffuse), ("metal", metal)):
+        pdf = np.array([s.mat_probe(m, n, v, d)[0] for d in dirs])
+        assert np.isfinite(pdf).all() and (pdf >= 0).all(), name
+        w, ok = s.mat_sample_probe(m, n, v, 11, 120000)
+        gaps[name] = [abs((h(w) * ok).mean() - (h(dirs) * pdf).sum() * dw) for h in tests]
+    assert max(gaps["diffuse"]) < 6e-3, gaps
+    assert gaps["metal"][0] == pytest.approx(0.0944, abs=0.01), gaps      # P(Some) 0.983 vs integral of pdf 0.889
+    s.close()
+
+
 def test_kat_camera_init(orc):   # a2: camera.rs:51-77
     s = orc.Scene()
     cam = s.build_scene(3, 600, 100)
