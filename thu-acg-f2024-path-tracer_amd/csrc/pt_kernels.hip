@@ -337,8 +337,9 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 //   phase A: every ray walks only the TOP-LEVEL tree; spheres / quads / cuboids are intersected on
 //            the spot, mesh instances whose box it enters are only RECORDED (<= 4 per ray, in LDS);
 //   phase B: the rays that recorded something are compacted into an LDS list and the block's waves
-//            pull them 64 at a time (work stealing): each lane walks the recorded meshes of its ray
-//            one after the other, starting from the phase-A best hit.
+//            draw from it (work stealing): each lane walks the recorded meshes of its ray one after
+//            the other, starting from the phase-A best hit, and takes the next ray of the list when
+//            it is done (lanes are refilled, a wave does not wait for the longest ray of a group).
 // Rays that never touch a mesh finish in the short, uniform phase A; the long mesh traversals run in
 // dense waves whose lanes all do the same kind of work. The closest hit is order-independent
 // (minimum t, ties -> larger id), so the result is bit-identical to the batch kernel's.
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
 // Tried and dropped: the two phases as two kernels with a global candidate list; every
 // wave on its own 256-slot window without block barriers; warming the next window's ray lines.
 constexpr int EXT_WINDOW = 2048;   // slots per block window
+constexpr uint32_t REFILL_MIN = 16;   // idle lanes that trigger a refill of the wave in phase B
 constexpr int EXT_CAND = 768;      // candidate list of a window (LDS); a fuller window walks the rest in phase A
 
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
@@ -502,23 +504,80 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         __syncthreads();
         // ---- phase B: mesh traversals, 64 rays per pull ------------------------------------------------
         const uint32_t n_rays = s_nrays < (uint32_t)EXT_CAND ? s_nrays : (uint32_t)EXT_CAND;
-        for (;;) {
-            uint32_t g = 0;
-            if (lane == 0) g = atomicAdd(&s_next, 1u);
-            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-            if (g * 64u >= n_rays) break;
-            const uint32_t idx = g * 64u + (uint32_t)lane;
-            if (idx < n_rays) {
-                const uint32_t sl = s_cand_sl[idx], slot = wbase + sl;
-                const RayD r = load_ray(pool, slot);
-                Closest best{s_cand_t[idx], s_best_id[sl]};
-                const uint32_t items = s_cand_items[idx];
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint32_t ei = (items >> (8u * k)) & 0xFFu;
-                    if (ei == 0xFFu) break;
-                    blas_pass(sc, r, sc.entries[ei], t_min, t_min_f, stk, EXT_STACK, best);
+        {
+            // Lanes are refilled: a lane whose ray is done does not wait for the longest ray of a fixed group of 64 —
+            // when at least REFILL_MIN lanes of the wave are idle they draw the next candidates from the list (one
+            // LDS atomic per wave) and the wave goes on with every lane at its own ray. s_next counts RAYS here.
+            bool busy = false, exhausted = false;                   // exhausted: wave-uniform, the list has run out
+            uint32_t sl = 0, items = 0, item_k = 0, cur = REF_EMPTY;
+            int sp = 0;
+            RayD wr{}, r{};
+            RayF f{};
+            Closest best{D_INF, HIT_NONE};
+            float t_max_f = 0.0f;
+            auto start_item = [&]() -> bool {                       // enters mesh number item_k of this lane's ray, if any
+                const uint32_t ei = item_k < 4u ? (items >> (8u * item_k)) & 0xFFu : 0xFFu;
+                if (ei == 0xFFu) return false;
+                const Entry e = sc.entries[ei];
+                r = wr;
+                if (e.inst >= 0) r = ray_to_local(sc.insts[e.inst], wr);
+                f = make_rayf(r.o, r.d, e.extent);
+                t_max_f = t_max_f32(best.t);
+                cur = e.blas_root;
+                sp = 0;
+                return true;
+            };
+            for (;;) {
+                const unsigned long long idle = __ballot(!busy);
+                const uint32_t n_idle = (uint32_t)__popcll(idle);
+                if (!exhausted && (n_idle >= REFILL_MIN || n_idle == 64u)) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_next, n_idle);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    exhausted = base + n_idle >= n_rays;
+                    if (!busy) {
+                        const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        if (idx < n_rays) {
+                            sl = s_cand_sl[idx];
+                            items = s_cand_items[idx];
+                            wr = load_ray(pool, wbase + sl);
+                            best = Closest{s_cand_t[idx], s_best_id[sl]};
+                            item_k = 0;
+                            busy = start_item();                    // a candidate always has at least one item
+                        }
+                    }
                 }
-                s_best_id[sl] = best.id;
+                if (__ballot(busy) == 0ull) {
+                    if (exhausted) break;
+                    continue;                                       // everybody idle: the refill above was forced, go again
+                }
+                // descend until every busy lane holds a triangle leaf or has run out of nodes in this mesh
+                while (busy && (cur & REF_TYPE_MASK) == REF_NODE) {
+                    uint32_t c0, c1;
+                    const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
+                    if (n == 2 && sp < EXT_STACK) stk[(sp++) * BLOCK] = c1;
+                    if (n > 0) cur = c0;
+                    else if (sp > 0) cur = stk[(--sp) * BLOCK];
+                    else cur = REF_EMPTY;
+                }
+                if (busy) {
+                    if ((cur & REF_TYPE_MASK) == REF_TRIS) {
+                        const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
+                        for (uint32_t i = first; i < first + count; ++i) {
+                            double t, u, v;
+                            if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
+                        }
+                        t_max_f = t_max_f32(best.t);
+                        cur = sp > 0 ? stk[(--sp) * BLOCK] : REF_EMPTY;
+                    }
+                    if (cur == REF_EMPTY) {                         // this mesh is done: the ray's next mesh, or the ray is done
+                        ++item_k;
+                        if (!start_item()) {
+                            s_best_id[sl] = best.id;
+                            busy = false;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
