@@ -109,7 +109,7 @@ inline Quat quat_normalize(Quat q) {
 }
 inline Quat quat_inverse(Quat q) { return {-q.x, -q.y, -q.z, q.w}; }  // conjugate (unit quat)
 inline Quat quat_from_axis_angle(V3 axis, double angle) {
-    double s = std::sin(angle * 0.5), c = std::cos(angle * 0.5);
+    double s = m_sin(angle * 0.5), c = m_cos(angle * 0.5);   // libm in the faithful mode, detmath in the det mode (like the product's host)
     V3 v = axis * s;
     return {v.x, v.y, v.z, c};
 }

@@ -265,11 +265,13 @@ def test_kernel_forms_and_pool_sizes_agree(pt, ctx):
         np.testing.assert_allclose(acc[fin], ref40[fin], rtol=1e-11, atol=1e-11, err_msg=str(env))
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 27, 45, 58])
 def test_random_scenes_bit_exact(pt, det, ctx, seed):
     """Fuzz: random spheres / moving spheres / quads / instanced cuboids / instanced meshes with random
-    diffuse, metal, glass and principled materials, checker textures, quad (+ sphere) lights."""
-    spec = random_scene(seed, sphere_light=(seed % 2 == 1))
+    diffuse, metal, glass, principled, sheen, clearcoat and mix materials, checker textures, quad (+ sphere)
+    lights. Seed 27 is the scene that exposed a one-ulp difference between the two hosts' instance matrices
+    (libm sincos() vs sin()+cos(); tools/gpu_fuzz.py runs the long soak)."""
+    spec = random_scene(seed, sphere_light=(seed % 2 == 1), n_objects=10 if seed < 4 else 6 + seed % 9)
     gs, os_ = pt.Scene(ctx), det.Scene()
     gres, ores = spec.replay(gs), spec.replay(os_)
     assert gs.prim_count() == os_.prim_count()

@@ -1,5 +1,6 @@
 // Scene builder + flattener + BVH builder (host). See pt_scene.h.
 #include "pt_scene.h"
+#include "pt_detmath.h"
 
 #include <hip/hip_runtime.h>
 
@@ -258,7 +259,11 @@ extern "C" int pt_instance(pt_scene* s, int obj, const double axis[3], double an
     o.kind = OBJ_INSTANCE;
     o.child = obj;
     // DQuat::from_axis_angle, DMat4::from_rotation_translation (glam 0.29 quat_to_axes)
-    double sn = std::sin(angle * 0.5), cs = std::cos(angle * 0.5);
+    // detmath, not libm: g++ turns a sin/cos pair into one sincos() call, clang keeps two calls, and glibc's sincos can
+    // differ from its sin and cos in the last bit on some CPUs — found by fuzzing (one instance angle in 40 scenes gave
+    // a rotation matrix one ulp off the oracle's). The shared implementation makes the transform machine-independent.
+    double sn, cs;
+    detmath::sincos(angle * 0.5, sn, cs);
     D3 v = d3(axis) * sn;
     double qx = v.x, qy = v.y, qz = v.z, qw = cs;
     double x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
