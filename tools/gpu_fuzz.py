@@ -1,5 +1,5 @@
 """One-off soak: random scenes (tests/common.random_scene) GPU vs oracle (det math), bit-exact, for a seed range.
-    python tools/gpu_fuzz.py 4 40
+    python tools/gpu_fuzz.py 4 40 [cam]
 """
 import importlib, os, sys
 import numpy as np
@@ -13,6 +13,12 @@ ctx = pt.Context(0)
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     spec = random_scene(seed, sphere_light=(seed % 2 == 1), n_objects=6 + seed % 9)
+    if len(sys.argv) > 3 and sys.argv[3] == "cam":        # also randomise the camera
+        r = np.random.default_rng(seed)
+        spec.camera.update(vfov=float(r.uniform(20, 95)), defocus_angle=float(r.uniform(0, 3)), focal_length=float(r.uniform(3, 9)),
+                           aspect_ratio=float(r.choice([1.0, 1.5, 0.7, 16 / 9])), image_width=int(r.integers(33, 80)),
+                           look_from=tuple(r.uniform([-3, 0.5, -7], [3, 3, -4])), blur_strength=float(r.uniform(0, 1)),
+                           max_depth=int(r.choice([3, 8, 50])))
     gs, os_ = pt.Scene(ctx), orc.Scene()
     gres, ores = spec.replay(gs), spec.replay(os_)
     gcam, ocam = spec.make_camera(pt.Camera, gres), spec.make_camera(orc.Camera, ores)
