@@ -34,6 +34,11 @@ B_SHADE_PER_SEGMENT = 92 + 4 + 92        # record in + closest primitive in + re
 B_FB_PER_SAMPLE = 24                     # 3 f64 accumulator add per finished sample
 
 
+SCENE_NOTE = {3: "reference main.rs scene script: Cornell box, quad light, one-sample MIS",
+              5: "reference main.rs scene script: 15 principled spheres, 7616x3808 environment map",
+              6: "reference main.rs scene script: bunny+spot+cow OBJ meshes, envmap"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +190,7 @@ def main():
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"scene {args.scene} (reference main.rs scene script: bunny+spot+cow OBJ meshes, envmap) {args.width}x{height} @ {args.spp} spp, max_depth 50, seed {args.seed}",
+            "config": {"workload": f"scene {args.scene} ({SCENE_NOTE.get(args.scene, 'reference main.rs scene script')}) {args.width}x{height} @ {args.spp} spp, max_depth 50, seed {args.seed}",
                        "parallelism": f"spp-sharded x{world}, one RCCL reduce of the f64 W*H*3 accumulator" if world > 1 else "single GPU",
                        "slots_per_pixel": stats[0]["slots_per_pixel"], "resident_paths": stats[0]["n_slots"],
                        "segments_per_sample": round(total_segments / max(total_samples, 1), 4), "scene_build_s": round(build_s, 3),

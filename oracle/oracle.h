@@ -112,6 +112,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 double orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);
 double orc_probe(int which, const double* args);
 /* pdf (out4[0]) and eval (out4[1..3]) of one material at a synthetic hit with normal n, uv (0.5,0.5) */
+void orc_mat_probe_front_face(int front);   /* front_face of the synthetic hit used by the two probes below (default 1) */
 int orc_mat_probe(orc_scene*, int mat, const double* n, const double* wo, const double* wi, double* out4);
 /* n_samples directions from BxDFMaterial::sample at the same synthetic hit: out = n x (dir xyz, 1 Some / 0 None) */
 int orc_mat_sample_probe(orc_scene*, int mat, const double* n, const double* wo, uint64_t seed, uint32_t n_samples, double* out);

@@ -158,11 +158,13 @@ extern "C" int orc_mat_clearcoat(orc_scene* s, double clearcoat_gloss) {
 }
 // material-level probe for the known-answer tests: pdf and eval of material `mat` at a hit with unit
 // normal n (geometric == shading), uv = (0.5, 0.5), for world-space view / light directions.
+static bool g_probe_front_face = true;   // HitInfo::front_face of the synthetic hit of the two probes below (hit_info.rs:24)
+extern "C" void orc_mat_probe_front_face(int front) { g_probe_front_face = front != 0; }
 extern "C" int orc_mat_probe(orc_scene* s, int mat, const double* n, const double* wo, const double* wi, double* out4) {
     if (mat < 0 || mat >= (int)s->mats.size()) return -1;
     HitInfo info{};
     info.geometric_normal = info.shading_normal = normalize(V3{n[0], n[1], n[2]});
-    info.front_face = true;
+    info.front_face = g_probe_front_face;
     info.u = info.v = 0.5;
     info.mat = s->mats[mat].get();
     V3 v{wo[0], wo[1], wo[2]}, l{wi[0], wi[1], wi[2]};
@@ -177,7 +179,7 @@ extern "C" int orc_mat_sample_probe(orc_scene* s, int mat, const double* n, cons
     if (mat < 0 || mat >= (int)s->mats.size()) return -1;
     HitInfo info{};
     info.geometric_normal = info.shading_normal = normalize(V3{n[0], n[1], n[2]});
-    info.front_face = true;
+    info.front_face = g_probe_front_face;
     info.u = info.v = 0.5;
     info.mat = s->mats[mat].get();
     V3 v = normalize(V3{wo[0], wo[1], wo[2]});

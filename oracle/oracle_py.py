@@ -168,14 +168,19 @@ class Scene:
     def mat_mix(self, t, m1, m2): return _check(lib.orc_mat_mix(self.handle, t, m1, m2))
     def mat_sheen(self, rgb, sheen_tint): return _check(lib.orc_mat_sheen(self.handle, rgb[0], rgb[1], rgb[2], sheen_tint))
     def mat_clearcoat(self, gloss): return _check(lib.orc_mat_clearcoat(self.handle, gloss))
-    def mat_sample_probe(self, mat, n, wo, seed, n_samples):
+    def mat_sample_probe(self, mat, n, wo, seed, n_samples, front=True):
         out = np.zeros((n_samples, 4), dtype=np.float64)
+        lib.orc_mat_probe_front_face(1 if front else 0)
         _check(lib.orc_mat_sample_probe(self.handle, mat, _d3(n), _d3(wo), seed, n_samples, out.ctypes.data))
+        lib.orc_mat_probe_front_face(1)
         return out[:, :3], out[:, 3] > 0
 
-    def mat_probe(self, mat, n, wo, wi):
+    def mat_probe(self, mat, n, wo, wi, front=True):
+        """(pdf, eval) at a synthetic hit with normal n; front = HitInfo::front_face (hit_info.rs:24)."""
         out = (C.c_double * 4)()
+        lib.orc_mat_probe_front_face(1 if front else 0)
         _check(lib.orc_mat_probe(self.handle, mat, _d3(n), _d3(wo), _d3(wi), out))
+        lib.orc_mat_probe_front_face(1)
         return out[0], np.array(out[1:4])
     def sphere(self, r, p1, p2, mat): return _check(lib.orc_sphere(self.handle, r, _d3(p1), _d3(p2), mat))
     def quad(self, q, u, v, mat): return _check(lib.orc_quad(self.handle, _d3(q), _d3(u), _d3(v), mat))

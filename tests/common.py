@@ -173,3 +173,59 @@ def demo_block_stats(scene_id, rgb8):
     d = np.abs(blocks - ref)[keep]
     corr = np.array([np.corrcoef(blocks[..., c][keep], ref[..., c][keep])[0, 1] for c in range(3)])
     return d.mean(axis=0), corr, blocks.mean(axis=(0, 1)), ref.mean(axis=(0, 1))
+
+
+# ---- the lights / MIS branch against deterministic quadrature (tests/refs_numpy.py) ---------------------------------
+# A Lambert floor under ONE emitter, camera straight above the floor and below the emitter, black environment,
+# max_depth = 2: the pixel value is E[brdf / (0.5 bsdf_pdf + 0.5 light_pdf) * Le] of trace()'s first bounce
+# (camera.rs:199-216, list.rs:78-96, quad.rs:80-98 / sphere.rs:110-135) and nothing else — quirk Q5 needs a third segment.
+MIS_ALBEDO, MIS_EMISSION = (0.8, 0.6, 0.4), (6.0, 5.0, 4.0)
+MIS_QUAD = ((-0.5, 2.0, -0.5), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+MIS_SPHERE = ((0.0, 2.0, 0.0), 0.4)
+MIS_CAM = dict(width=24, aspect=1.0, vfov=50.0, look_from=(0.0, 1.0, 0.0), look_at=(0.0, 0.0, 0.0), vup=(0.0, 0.0, 1.0), focal_length=1.0)
+
+
+def mis_scene(light):
+    s = SceneSpec()
+    floor = s.add("mat_diffuse", s.add("tex_solid_rgb", *MIS_ALBEDO), -1)
+    s.add("world_add_object", s.add("quad", (-4.0, 0.0, -4.0), (0.0, 0.0, 8.0), (8.0, 0.0, 0.0), floor))
+    lm = s.add("mat_light", s.add("tex_solid_rgb", *MIS_EMISSION))
+    if light == "quad":
+        s.add("world_add_light", s.add("quad", *MIS_QUAD, lm))
+    else:
+        s.add("world_add_light", s.add("sphere", MIS_SPHERE[1], MIS_SPHERE[0], MIS_SPHERE[0], lm))
+    s.add("world_build")
+    c = MIS_CAM
+    s.camera = default_camera(width=c["width"], aspect=c["aspect"], spp=1, max_depth=2, vfov=c["vfov"], look_from=c["look_from"], look_at=c["look_at"],
+                              vup=c["vup"], focal_length=c["focal_length"], defocus_angle=0.0, blur_strength=0.5, env_color=(0.0, 0.0, 0.0))
+    return s
+
+
+def mis_expected(light):
+    """Per-pixel expectation (H, W, 3) of the reference's estimator by quadrature, and the true integral (same thing for
+    the quad light; for the sphere light the reference's estimator is biased and both are returned)."""
+    import refs_numpy as R
+    c = MIS_CAM
+    fr = R.camera_frame(c["width"], c["aspect"], c["vfov"], c["look_from"], c["look_at"], c["vup"], c["focal_length"])
+    H, W = fr["height"], c["width"]
+    rows, cols = np.divmod(np.arange(H * W), W)
+    off = R.pixel_footprint()
+    pts = R.floor_points(fr, rows, cols, off).reshape(-1, 3)
+    pts = pts + np.array([0.0, 1e-3, 0.0])          # the second segment starts EPS above the surface (camera.rs:217-222)
+    if light == "quad":
+        est = true = R.quad_light_floor_radiance(pts, MIS_ALBEDO, MIS_EMISSION, *MIS_QUAD)
+    else:
+        est, true = R.sphere_light_floor_radiance(pts, MIS_ALBEDO, MIS_EMISSION, *MIS_SPHERE)
+    shape = (H, W, len(off), 3)
+    return est.reshape(shape).mean(axis=2), true.reshape(shape).mean(axis=2)
+
+
+def mis_zscores(render, expected, n_batches=16, spp_per_batch=256, seed=3):
+    """render(seed, spp_begin, spp_end) -> sum accumulator (H, W, 3). Returns (z per pixel and channel, z of the image mean, mean image)."""
+    batches = np.stack([render(seed, k * spp_per_batch, (k + 1) * spp_per_batch) / spp_per_batch for k in range(n_batches)])
+    mean = batches.mean(axis=0)
+    sem = batches.std(axis=0, ddof=1) / np.sqrt(n_batches)
+    z = (mean - expected) / sem
+    g = batches.mean(axis=(1, 2))                                      # (n_batches, 3) image means
+    zg = (g.mean(axis=0) - expected.mean(axis=(0, 1))) / (g.std(axis=0, ddof=1) / np.sqrt(n_batches))
+    return z, zg, mean

@@ -205,23 +205,25 @@ PT_DEV V3 lights_sample(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
 PT_DEV double lights_pdf(const SceneD& sc, V3 origin_w, V3 direction_w, double time) {
     if (sc.n_lights == 0) return 0.0;
     double sum = 0.0;
-    for (uint32_t i = 0; i < sc.n_lights; ++i) {
-        const Entry e = sc.entries[sc.lights[i]];
+    for (uint32_t i = 0; i < sc.n_lights; ++i) {                                  // the light index is wave-uniform: scalar loads (ldu)
+        const Entry e = ldu(&sc.entries[ldu(&sc.lights[i])]);
         V3 origin = origin_w, direction = direction_w;
         if (e.inst >= 0) {                                                        // instance.rs:71-75
-            const InstD& m = sc.insts[e.inst];
+            const InstD m = ldu(&sc.insts[e.inst]);
             origin = xform_point(m.i0, m.i1, m.i2, m.it, origin_w);
             direction = xform_vector(m.i0, m.i1, m.i2, direction_w);
         }
         double pdf = 0.0;
         if (e.kind == ENTRY_QUAD) {
-            const PrimRef pr = sc.prims[e.first_prim];
-            pdf = pdf_quad(sc, sc.quads[pr.index], pr.mat, origin, direction, time);
+            const PrimRef pr = ldu(&sc.prims[e.first_prim]);
+            const QuadD qd = ldu(&sc.quads[pr.index]);
+            pdf = pdf_quad(sc, qd, pr.mat, origin, direction, time);
         } else if (e.kind == ENTRY_CUBOID) {                                      // list.rs:86-96 over the six sides
             double s6 = 0.0;
             for (uint32_t j = 0; j < 6u; ++j) {
-                const PrimRef pr = sc.prims[e.first_prim + j];
-                s6 += pdf_quad(sc, sc.quads[pr.index], pr.mat, origin, direction, time);
+                const PrimRef pr = ldu(&sc.prims[e.first_prim + j]);
+                const QuadD qd = ldu(&sc.quads[pr.index]);
+                s6 += pdf_quad(sc, qd, pr.mat, origin, direction, time);
             }
             pdf = s6 / 6.0;
         } else if (e.kind == ENTRY_MESH) {                                        // list.rs:86-96 over ALL triangles (O(n), like the reference)
@@ -304,7 +306,7 @@ PT_DEV V3 sample_environment(const SceneD& sc, const CamD& cam, V3 d) {
     double phi = detmath::atan2(d.z, d.x);
     double u = (phi + D_PI) / (2.0 * D_PI);
     double v = 1.0 - theta / D_PI;
-    return tex_image(sc, sc.tex[cam.env_tex], u, v);
+    return tex_image(sc, ldu(&sc.tex[cam.env_tex]), u, v);   // the environment's descriptor is the same for every lane
 }
 
 }  // namespace pt

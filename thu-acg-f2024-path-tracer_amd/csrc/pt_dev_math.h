@@ -66,6 +66,23 @@ PT_DEV V3 refract(V3 i, V3 n, double eta) {
 }
 PT_DEV double luminance(V3 c) { return 0.2126 * c.x + 0.7152 * c.y + 0.0722 * c.z; }
 
+// Wave-uniform read of read-only scene data. The kernels also STORE to global memory (the path pool), so the compiler
+// cannot prove that a plain load with a uniform address is never clobbered and issues a vector load for it: every lane
+// fetches the same bytes into VGPRs. Read through the constant address space the same access becomes a scalar load
+// (s_load_dwordxN): the operand stays in SGPRs, costs no vector-memory instruction and no vector registers. The scene
+// tables are written by the host before the launch and never by a kernel. `p` MUST be wave-uniform.
+template <class T> PT_DEV T ldu(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized records only");
+    typedef const __attribute__((address_space(4))) uint32_t* cptr;
+    cptr q = (cptr)p;
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = q[i];
+    T v;
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
+}
+
 // Shading frame: the shortest-arc quaternion taking n onto +z (vec3.rs:23-29). It is built
 // once per (normal) and reused for every to_local/to_world of a bounce — the reference
 // rebuilds it 4-7x per bounce with identical inputs, so reuse changes no bit.

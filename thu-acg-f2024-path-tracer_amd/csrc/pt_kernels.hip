@@ -12,6 +12,8 @@
 // VALU issue and L2 latency, with the path pool streaming through HBM once per stage.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pt_dev_geom.h"
 #include "pt_kernels.h"
 
@@ -151,17 +153,27 @@ PT_DEV int visit_node(const BvhNode* nd, const RayF& f, float t_min, float t_max
 }
 PT_DEV float t_max_f32(double t) { return __double2float_ru(t); }   // rounded UP: conservative upper end
 
+// U: `gid` is wave-uniform (the flat top-level walk) -> the primitive's record arrives by scalar loads (ldu)
+template <bool U = false>
 PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint32_t gid, Closest& best) {
-    const PrimRef pr = sc.prims[gid];
+    PrimRef pr;
+    if constexpr (U) pr = ldu(&sc.prims[gid]); else pr = sc.prims[gid];
     if ((pr.kind & 0xFFu) == PRIM_SPHERE) {
         double t;
         V3 c;
-        if (hit_sphere(sc.spheres[pr.index], r, t_min, t, c)) consider(best, t, gid);
+        bool h;
+        if constexpr (U) { const SphereD sp = ldu(&sc.spheres[pr.index]); h = hit_sphere(sp, r, t_min, t, c); }
+        else h = hit_sphere(sc.spheres[pr.index], r, t_min, t, c);
+        if (h) consider(best, t, gid);
     } else {
         double t, a, b;
-        if (hit_quad(sc.quads[pr.index], r, t_min, t, a, b)) consider(best, t, gid);
+        bool h;
+        if constexpr (U) { const QuadD qd = ldu(&sc.quads[pr.index]); h = hit_quad(qd, r, t_min, t, a, b); }
+        else h = hit_quad(sc.quads[pr.index], r, t_min, t, a, b);
+        if (h) consider(best, t, gid);
     }
 }
+struct Box6 { float lo[3], hi[3]; };   // SceneD::entry_box record
 
 template <bool F32>
 PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uint32_t* stk /* &stack[0][lane] */) {
@@ -285,19 +297,19 @@ PT_DEV Closest closest_hit_flat(const SceneD& sc, bool alive, const RayD& r, dou
     float t_max_f = t_max_f32(best.t);
     const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
     for (uint32_t ei = 0; ei < sc.n_entries; ++ei) {
-        const float* bx = sc.entry_box + 6u * ei;
+        const Box6 bx = ldu(reinterpret_cast<const Box6*>(sc.entry_box) + ei);
         float tn;
-        const bool hb = alive && slab_f32(bx, bx + 3, f, t_min_f, t_max_f, tn);
+        const bool hb = alive && slab_f32(bx.lo, bx.hi, f, t_min_f, t_max_f, tn);
         if (__ballot(hb) == 0ull) continue;
-        const Entry e = sc.entries[ei];
+        const Entry e = ldu(&sc.entries[ei]);
         if (hb) {
             if (e.kind == ENTRY_MESH) {
                 blas_pass(sc, r, e, t_min, t_min_f, stk, TRAVERSAL_STACK, best);
             } else {
                 RayD lr = r;
-                if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
+                if (e.inst >= 0) lr = ray_to_local(ldu(&sc.insts[e.inst]), r);
                 const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
-                for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+                for (uint32_t i = 0; i < n; ++i) test_world_prim<true>(sc, lr, t_min, e.first_prim + i, best);
             }
             t_max_f = t_max_f32(best.t);
         }
@@ -431,7 +443,8 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 f = make_rayf(r.o, r.d, sc.tlas_extent);
             }
             // one world entry whose box the ray enters: meshes are recorded, everything else is tested on the spot
-            auto visit_entry = [&](uint32_t ei, const Entry& e, int sp) {
+            auto visit_entry = [&](auto uniform, uint32_t ei, const Entry& e, int sp) {   // uniform: ei is the same in every lane
+                constexpr bool U = decltype(uniform)::value;
                 if (e.kind == ENTRY_MESH) {
                     if (n_my < 4u && ei < 0xFFu) {
                         items = (items & ~(0xFFu << (8u * n_my))) | (ei << (8u * n_my));   // defer to phase B
@@ -442,9 +455,12 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                     }
                 } else {
                     RayD lr = r;
-                    if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
+                    if (e.inst >= 0) {
+                        if constexpr (U) lr = ray_to_local(ldu(&sc.insts[e.inst]), r);
+                        else lr = ray_to_local(sc.insts[e.inst], r);
+                    }
                     const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;       // cuboid.rs: six quads, linear
-                    for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
+                    for (uint32_t i = 0; i < n; ++i) test_world_prim<U>(sc, lr, t_min, e.first_prim + i, best);
                     t_max_f = t_max_f32(best.t);
                 }
             };
@@ -453,12 +469,12 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 // The entry index is wave-uniform, so boxes, entries and instance transforms arrive by scalar
                 // loads, there is no stack, and an entry no lane's ray enters costs one box test.
                 for (uint32_t ei = 0; ei < sc.n_entries; ++ei) {
-                    const float* bx = sc.entry_box + 6u * ei;
+                    const Box6 bx = ldu(reinterpret_cast<const Box6*>(sc.entry_box) + ei);
                     float tn;
-                    const bool hb = alive && slab_f32(bx, bx + 3, f, t_min_f, t_max_f, tn);
+                    const bool hb = alive && slab_f32(bx.lo, bx.hi, f, t_min_f, t_max_f, tn);
                     if (__ballot(hb) == 0ull) continue;
-                    const Entry e = sc.entries[ei];
-                    if (hb) visit_entry(ei, e, 0);
+                    const Entry e = ldu(&sc.entries[ei]);
+                    if (hb) visit_entry(std::true_type{}, ei, e, 0);
                 }
             } else if (alive) {
                 int sp = 0;
@@ -474,7 +490,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                         }
                     } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
                         const uint32_t ei = cur & 0x3FFFFFFFu;
-                        visit_entry(ei, sc.entries[ei], sp);
+                        visit_entry(std::false_type{}, ei, sc.entries[ei], sp);
                     }
                     if (sp == 0) break;
                     cur = stk[(--sp) * BLOCK];
