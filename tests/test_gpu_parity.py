@@ -499,3 +499,26 @@ def test_cli_renders_scene3_like_the_reference_binary(pt, det, ctx, tmp_path):
     bad = subprocess.run([exe, "-s", "5", "--width", "32", "--spp", "1", "--assets", "/nonexistent"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 101 and "panic" in bad.stderr                         # asset errors are fatal like unwrap()
     os_.close()
+
+
+# ---- the lights / MIS branch against deterministic quadrature (no reference image exists for scenes with lights) ----------
+@pytest.mark.parametrize("light", ["quad", "sphere"])
+def test_light_sampling_mis_matches_quadrature(pt, ctx, light):
+    """The HIP path's one-sample MIS (camera.rs:199-216, list.rs:78-96, quad.rs:80-98 / sphere.rs:110-135) against numbers
+    that come from neither the oracle nor the kernels: tests/refs_numpy.py integrates what trace() computes in expectation
+    for a Lambert floor under one emitter (max_depth = 2, so quirk Q5 cannot act). Quad light: the estimator is unbiased and
+    the pixel must equal (albedo/pi) Le x form factor. Sphere light: the reference's Sphere::pdf is not the density of
+    Sphere::sample — its estimator is ~18x too bright — and THAT value must be reproduced. Every pixel within Monte-Carlo
+    error (16 batches of 256 spp: z ~ t(15)), the image mean within 4 sigma."""
+    from common import mis_scene, mis_expected, mis_zscores
+    spec = mis_scene(light)
+    gs = pt.Scene(ctx)
+    cam = spec.make_camera(pt.Camera, spec.replay(gs))
+    est, true = mis_expected(light)
+    z, zg, mean = mis_zscores(lambda seed, a, b: gs.render(cam, seed, a, b)[0], est)
+    gs.close()
+    assert np.isfinite(z).all()
+    assert np.abs(zg).max() < 4.0, zg
+    assert (np.abs(z) > 4.0).mean() < 0.01 and 0.85 < z.std() < 1.3, (np.abs(z).max(), z.std())
+    if light == "sphere":
+        assert mean.mean() > 10.0 * true.mean()
