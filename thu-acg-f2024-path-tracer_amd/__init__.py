@@ -19,7 +19,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libpt_amd.so")
+# PT_AMD_LIB: A/B measurements of two builds of the library in one session (tools/ab_perf.sh); never a different backend
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "libpt_amd.so")
 ASSET_DIR = os.path.join(REPO_ROOT, "assets")
 
 

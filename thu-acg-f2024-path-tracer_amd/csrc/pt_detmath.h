@@ -4,17 +4,27 @@
 // implementations into a visibly different sample (the 3-D checker on the y = 0 ground plane
 // floors a coordinate that is 0 +- 1e-16, texture.rs:44-48; the light-plane offset sign,
 // camera.rs:217). With these functions the GPU kernels and the CPU oracle (in its "det" math
-// mode) execute the SAME sequence of IEEE-754 operations (+ - * / sqrt, no FMA, no tables
-// beyond the listed constants), so their results agree bit for bit and parity tests can
-// demand equality instead of a tolerance.
+// mode) execute the SAME sequence of IEEE-754 operations (+ - * / sqrt and fma — each exactly
+// specified, so a hardware fma on the GPU and on the CPU give the same bits; no tables beyond
+// the listed constants), so their results agree bit for bit and parity tests can demand
+// equality instead of a tolerance.
 //
-// Algorithms: the classic fdlibm (Sun Microsystems, freely redistributable) kernels —
-// k_sin/k_cos with a 3-part Cody-Waite reduction (valid for |x| < 2^19*pi/2; larger or
-// non-finite arguments, which the renderer never produces, fall back to an fmod-style
-// reduction), e_acos, s_atan/e_atan2, e_log, e_exp. log2(x) = log(x)/ln2 and
-// pow(x,y) = exp(y*log(x)) (x > 0) are composed from those (<= 4 ulp for |y log x| <= 4; the
-// renderer only calls pow(0.0625, y), y in (0,1]). Accuracy of each is pinned against glibc
-// in tests/test_detmath.py.
+// Algorithms: fdlibm's (Sun Microsystems, freely redistributable) 3-part Cody-Waite reduction
+// (valid for |x| < 2^19*pi/2; larger or non-finite arguments, which the renderer never
+// produces, fall back to an fmod-style reduction), e_acos, s_atan/e_atan2, e_log, e_exp with
+// their polynomials evaluated by fma; log2(x) = log(x)/ln2 and pow(x,y) = exp(y*log(x)) (x > 0)
+// are composed from those (<= 4 ulp for |y log x| <= 4; the renderer only calls pow(0.0625, y),
+// y in (0,1]).
+// sin / cos have their own kernels (round 2): the two leading terms of each series are carried
+// in double-double (error-free products by fma, Fast2Sum), the rest is a degree-5 polynomial in
+// x^2 fitted at 120 digits (tools/make_detmath_coeffs.py; approximation error 2^-64), and the
+// result is rounded ONCE — it is the correctly rounded value in all but ~0.3 % of the calls.
+// Why that matters: glibc's sin/cos (what the Rust reference calls) are correctly rounded in
+// 99.87 % of calls, fdlibm's kernels in 96.5 %; every last-bit difference of a sampled
+// direction can flip a checker cell or an offset sign further down the path, and with the
+// fdlibm kernels the image RMSE against the libm-mode oracle at 4000 spp was 1.6e-4 on
+// scene 6 — above north_star's 1e-4 (tests/test_gpu_parity.py::test_north_star_tolerance).
+// Accuracy of each function is pinned against glibc in tests/test_detmath.py.
 //
 // This file is compiled for host and device; oracle/orc_detmath.h is a verbatim copy (the
 // oracle may not include product headers and vice versa; a test keeps the two in sync).
@@ -47,31 +57,54 @@ PT_DM double dm_nan() { return dm_from_bits(0x7FF8000000000000ull); }
 PT_DM double dm_sqrt(double x) { return __builtin_sqrt(x); }   // IEEE correctly rounded on both sides
 
 // ---- sin / cos ------------------------------------------------------------------------
-PT_DM double dm_ksin(double x, double y, int iy) {   // |x| <= pi/4, y = tail
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double z = x * x;
-    double v = z * x;
-    double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    if (iy == 0) return x + v * (S1 + z * r);
-    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+PT_DM double dm_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// sin(x + y), |x| <= pi/4 (+ slack), y = tail of the reduced argument.
+//   sin x = x - x^3/6 + x^5 P(z), z = x^2. x^2, x^3 and x^3 * (-1/6) are double-double; the sum is rounded once.
+PT_DM double dm_ksin(double x, double y) {
+    const double S1h = -0x1.5555555555555p-3, S1l = -0x1.5555555555555p-57;   // -1/6
+    const double P0 = 0x1.1111111111111p-7, P1 = -0x1.a01a01a019ed6p-13, P2 = 0x1.71de3a550cb3ap-19, P3 = -0x1.ae6455341c2b5p-26,
+                 P4 = 0x1.61225b335745dp-33, P5 = -0x1.ab93f5e6a14a5p-41;
+    if ((dm_hi(x) & 0x7fffffff) < 0x3e500000) return x;   // |x| < 2^-26: x^3/6 is below half an ulp (keeps -0)
+    const double zh = x * x;
+    const double zl = dm_fma(x, x, -zh);                      // x^2 = zh + zl exactly
+    double p = dm_fma(P5, zh, P4);
+    p = dm_fma(p, zh, P3);
+    p = dm_fma(p, zh, P2);
+    p = dm_fma(p, zh, P1);
+    p = dm_fma(p, zh, P0);
+    const double wh = x * zh;
+    const double wl = dm_fma(x, zh, -wh) + x * zl;            // x^3 = wh + wl
+    const double ch = wh * S1h;
+    const double cl = dm_fma(wh, S1h, -ch) + (wh * S1l + wl * S1h);   // -x^3/6 = ch + cl
+    const double q = (wh * zh) * p;                           // x^5 P(z)
+    const double t = dm_fma(-0.5 * zh, y, y);                 // sin(x+y) - sin(x) ~ y cos x ~ y (1 - z/2)
+    const double sh = x + ch;
+    const double sl = (x - sh) + ch;                          // Fast2Sum, |x| >= |ch|
+    return sh + (sl + (cl + (q + t)));
 }
+// cos(x + y): cos x = 1 - z/2 + z^2/24 + z^3 Q(z); z/2, z^2 and z^2/24 are double-double.
 PT_DM double dm_kcos(double x, double y) {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    int32_t ix = dm_hi(x) & 0x7fffffff;
-    if (ix < 0x3e400000) {
-        if ((int)x == 0) return 1.0;
-    }
-    double z = x * x;
-    double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-    if (ix < 0x3FD33333) return 1.0 - (0.5 * z - (z * r - x * y));
-    double qx;
-    if (ix > 0x3fe90000) qx = 0.28125;
-    else qx = dm_words(ix - 0x00200000, 0);
-    double hz = 0.5 * z - qx;
-    double a = 1.0 - qx;
-    return a - (hz - (z * r - x * y));
+    const double C2h = 0x1.5555555555555p-5, C2l = 0x1.5555555555555p-59;     // 1/24
+    const double Q0 = -0x1.6c16c16c16c17p-10, Q1 = 0x1.a01a01a019f8ap-16, Q2 = -0x1.27e4fb775f620p-22, Q3 = 0x1.1eed8e6c45572p-29,
+                 Q4 = -0x1.93957ddf1b130p-37, Q5 = 0x1.abe6c47d7a407p-45;
+    const double zh = x * x;
+    const double zl = dm_fma(x, x, -zh);
+    double q = dm_fma(Q5, zh, Q4);
+    q = dm_fma(q, zh, Q3);
+    q = dm_fma(q, zh, Q2);
+    q = dm_fma(q, zh, Q1);
+    q = dm_fma(q, zh, Q0);
+    const double wh = zh * zh;
+    const double wl = dm_fma(zh, zh, -wh) + (2.0 * zh) * zl;  // z^2 = wh + wl
+    const double dh = wh * C2h;
+    const double dl = dm_fma(wh, C2h, -dh) + (wh * C2l + wl * C2h);   // z^2/24 = dh + dl
+    const double r = (wh * zh) * q;                           // z^3 Q(z)
+    const double h = 0.5 * zh;
+    const double ah = 1.0 - h;
+    const double al = (1.0 - ah) - h;                         // Fast2Sum, 1 >= h
+    const double bh = ah + dh;
+    const double bl = (ah - bh) + dh;                         // Fast2Sum, ah >= 0.69 > dh
+    return bh + (bl + (al + ((dl - 0.5 * zl) + (r - x * y))));   // cos(x+y) - cos(x) ~ -y sin x ~ -x y
 }
 // argument reduction: x = n*(pi/2) + (y0 + y1), returns n mod 4 ... (n as int)
 PT_DM int dm_rem_pio2(double x, double& y0, double& y1) {
@@ -105,7 +138,7 @@ PT_DM int dm_rem_pio2(double x, double& y0, double& y1) {
     // medium size: Cody-Waite with up to three 33-bit pieces of pi/2
     int32_t n = (int32_t)(ax * invpio2 + 0.5);
     double fn = (double)n;
-    double r = ax - fn * pio2_1;
+    double r = dm_fma(-fn, pio2_1, ax);   // fn * pio2_1 is exact (33-bit constant), fused only to save an instruction
     double w = fn * pio2_1t;
     int32_t j = (dm_hi(ax) & 0x7fffffff) >> 20;
     y0 = r - w;
@@ -138,11 +171,11 @@ PT_DM void sincos(double x, double& s, double& c) {
     int n = dm_rem_pio2(x, y0, y1);
     int32_t ix = dm_hi(x) & 0x7fffffff;
     if (ix <= 0x3fe921fb) {
-        s = dm_ksin(x, 0.0, 0);
+        s = dm_ksin(x, 0.0);
         c = dm_kcos(x, 0.0);
         return;
     }
-    double ks = dm_ksin(y0, y1, 1), kc = dm_kcos(y0, y1);
+    double ks = dm_ksin(y0, y1), kc = dm_kcos(y0, y1);
     switch (n & 3) {
     case 0: s = ks; c = kc; break;
     case 1: s = kc; c = -ks; break;
@@ -172,29 +205,29 @@ PT_DM double acos(double x) {
     if (ix < 0x3fe00000) {   // |x| < 0.5
         if (ix <= 0x3c600000) return pio2_hi + pio2_lo;
         double z = x * x;
-        double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        double p = z * dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, pS5, pS4), pS3), pS2), pS1), pS0);
+        double q = dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, qS4, qS3), qS2), qS1), 1.0);
         double r = p / q;
-        return pio2_hi - (x - (pio2_lo - x * r));
+        return pio2_hi - (x - dm_fma(-x, r, pio2_lo));
     }
     if (hx < 0) {   // x < -0.5
         double z = (1.0 + x) * 0.5;
-        double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        double p = z * dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, pS5, pS4), pS3), pS2), pS1), pS0);
+        double q = dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, qS4, qS3), qS2), qS1), 1.0);
         double s = dm_sqrt(z);
         double r = p / q;
-        double w = r * s - pio2_lo;
+        double w = dm_fma(r, s, -pio2_lo);
         return pi - 2.0 * (s + w);
     }
     // x > 0.5
     double z = (1.0 - x) * 0.5;
     double s = dm_sqrt(z);
     double df = dm_words(dm_hi(s), 0);
-    double c = (z - df * df) / (s + df);
-    double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-    double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    double c = dm_fma(-df, df, z) / (s + df);
+    double p = z * dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, pS5, pS4), pS3), pS2), pS1), pS0);
+    double q = dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, qS4, qS3), qS2), qS1), 1.0);
     double r = p / q;
-    double w = r * s + c;
+    double w = dm_fma(r, s, c);
     return 2.0 * (df + w);
 }
 
@@ -221,21 +254,21 @@ PT_DM double atan(double x) {
     } else {
         x = dm_abs(x);
         if (ix < 0x3ff30000) {   // |x| < 1.1875
-            if (ix < 0x3fe60000) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); }
+            if (ix < 0x3fe60000) { id = 0; x = dm_fma(2.0, x, -1.0) / (2.0 + x); }
             else { id = 1; x = (x - 1.0) / (x + 1.0); }
         } else {
-            if (ix < 0x40038000) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); }
+            if (ix < 0x40038000) { id = 2; x = (x - 1.5) / dm_fma(1.5, x, 1.0); }
             else { id = 3; x = -1.0 / x; }
         }
     }
     double z = x * x;
     double w = z * z;
-    double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
-    double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (id < 0) return x - x * (s1 + s2);
+    double s1 = z * dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, aT10, aT8), aT6), aT4), aT2), aT0);
+    double s2 = w * dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, aT9, aT7), aT5), aT3), aT1);
+    if (id < 0) return dm_fma(-x, s1 + s2, x);
     double ahi = id == 0 ? hi0 : id == 1 ? hi1 : id == 2 ? hi2 : hi3;
     double alo = id == 0 ? lo0 : id == 1 ? lo1 : id == 2 ? lo2 : lo3;
-    z = ahi - ((x * (s1 + s2) - alo) - x);
+    z = ahi - (dm_fma(x, s1 + s2, -alo) - x);
     return hx < 0 ? -z : z;
 }
 PT_DM double atan2(double y, double x) {
@@ -329,8 +362,8 @@ PT_DM double log(double x) {
     i = hx - 0x6147a;
     double w = z * z;
     int32_t j = 0x6b851 - hx;
-    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double t1 = w * dm_fma(w, dm_fma(w, Lg6, Lg4), Lg2);
+    double t2 = z * dm_fma(w, dm_fma(w, dm_fma(w, Lg7, Lg5), Lg3), Lg1);
     i |= j;
     double R = t2 + t1;
     if (i > 0) {
@@ -378,7 +411,7 @@ PT_DM double exp(double x) {
         return 1.0 + x;
     }
     double t = x * x;
-    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    double c = dm_fma(-t, dm_fma(t, dm_fma(t, dm_fma(t, dm_fma(t, P5, P4), P3), P2), P1), x);
     if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
     double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
     if (k >= -1021) return dm_words(dm_hi(y) + (int32_t)((uint32_t)k << 20), dm_lo(y));
