@@ -4,8 +4,12 @@ BASELINE.json's headline config: scene 6 (OBJ meshes + envmap), 1920x1080 @ 4000
 
 One "step" = one complete pass of the hot path over one frame: every rank renders its contiguous
 slice of the 4000 samples of every pixel (spp sharding, strong scaling: total work is fixed) into
-its own SUM accumulator, then ONE reduce (RCCL over xGMI, via torch.distributed's "nccl" backend)
-adds the accumulators on rank 0. N=1 renders all 4000 spp on one GPU and does no collective.
+its own device SUM accumulator, then ONE ncclReduce (RCCL over xGMI, called by libpt_amd.so itself:
+pt_render_multi — no torch in the data path or anywhere else in this script) adds the accumulators
+on rank 0. N=1 renders all 4000 spp on one GPU through the same entry point with a 1-rank
+communicator and does no collective. The timed region is bracketed by a communicator barrier +
+device synchronize on both sides (pt_comm_barrier) and the MAX over ranks of the elapsed time is
+what the value is computed from.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--spp 4000] [--width 1920] [--scene 6]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -87,6 +91,24 @@ def cpu_baseline(scene_id, width, seconds, images):
             "cpu": cpu_name, "segments_per_sample": round(cnt["segments"] / cnt["samples"], 4)}
 
 
+def frame_check(pt, ctx, args, acc, height):
+    """Sanity of the LAST timed frame (cheap, outside the timed region): finite, non-negative, right sample count and —
+    for scenes the reference ships a render of — its 48x27 block means against demo/*.png (tests/golden)."""
+    res = {"finite": bool(np.isfinite(acc).all()), "min": float(np.nanmin(acc)), "mean_linear": [round(float(x), 6) for x in acc.mean(axis=(0, 1)) / max(args.spp, 1)]}
+    gold = os.path.join(ROOT, "tests", "golden", "reference_demo_blocks.npz")
+    if os.path.exists(gold) and height % 27 == 0 and args.width % 48 == 0:
+        ref = np.load(gold)
+        key = f"scene{args.scene}"
+        if key in ref.files:
+            img = ctx.resolve_u8(acc, args.spp).astype(np.float64) / 255.0
+            blocks = img.reshape(27, height // 27, 48, args.width // 48, 3).mean(axis=(1, 3))
+            keep = np.ones((27, 48), dtype=bool)
+            if args.scene == 6:
+                keep[1:13, 27:36] = False        # the "spot" mesh of demo/scene6.png predates the mounted commit (DESIGN.md §2)
+            res["reference_demo_block_mad"] = [round(float(x), 5) for x in np.abs(blocks - ref[key])[keep].mean(axis=0)]
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -94,65 +116,43 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    dist = None
-    torch = None
-    force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"     # exercise the N>1 code path with one rank (1-GPU boxes)
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    import parallel_spp
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC between the ranks' processes (RCCL)
 
     pt = importlib.import_module("thu-acg-f2024-path-tracer_amd")
     ctx = pt.Context(local_rank)                       # fails loudly without a GPU
+    # rendezvous file of THIS launch: MASTER_PORT + the launcher's pid (the same for every rank of one torchrun)
+    id_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pt_amd_rccl_id_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    if rank == 0 and world > 1 and os.path.exists(id_path):
+        os.unlink(id_path)
+    comm = pt.Comm(ctx, rank, world, id_path if world > 1 else None)
     scene = pt.Scene(ctx)
     t0 = time.time()
     cam = scene.build_scene(args.scene, args.width, args.spp)
     build_s = time.time() - t0
     height = pt.image_height(cam)
-    lo, hi = parallel_spp.shard_range(args.spp, rank, world)
     n_pix = args.width * height
-    use_dist = world > 1 or force_dist
-    dev_accum = torch.zeros((height, args.width, 3), dtype=torch.float64, device="cuda") if use_dist else None
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
 
     def step(profile):
-        acc, st = scene.render(cam, args.seed, lo, hi, slots_per_pixel=args.slots_per_pixel, profile=profile)
-        if use_dist:
-            dev_accum.copy_(torch.from_numpy(acc))
-            parallel_spp.reduce_accum_to_root(dev_accum)     # the single RCCL collective of the frame
-            torch.cuda.synchronize()
-        return acc, st
+        return scene.render_multi(cam, args.seed, args.spp, comm, slots_per_pixel=args.slots_per_pixel, profile=profile)
 
     for _ in range(args.warmup):
         step(False)
-    barrier()
+    comm.barrier()
     t_start = time.perf_counter()
     stats = []
+    acc = None
     for _ in range(args.steps):
         acc, st = step(True)
         stats.append(st.as_dict())
-    barrier()
+    comm.barrier()
     elapsed = time.perf_counter() - t_start
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        seg = torch.tensor([sum(s["segments"] for s in stats), sum(s["samples"] for s in stats)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(seg)
-        total_segments, total_samples = seg.tolist()
-    else:
-        total_segments = sum(s["segments"] for s in stats)
-        total_samples = sum(s["samples"] for s in stats)
+    elapsed = float(comm.allreduce([elapsed], "max")[0])
+    total_segments, total_samples = comm.allreduce([sum(s["segments"] for s in stats), sum(s["samples"] for s in stats)], "sum")
+    if rank == 0 and world > 1:
+        try:
+            os.unlink(id_path)
+        except OSError:
+            pass
 
     if rank == 0:
         samples_per_step = n_pix * args.spp
@@ -171,15 +171,20 @@ def main():
             bytes_total = my_seg * B_SHADE_PER_SEGMENT + my_smp * B_FB_PER_SAMPLE
         avg_ms = kms / max(kn, 1)
         achieved = (bytes_total / max(kn, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from separate
+        # `rocprofv3 --pmc` passes over this same command (tools/run_profiles.sh -> profiles/pmc_latest.json). The value is
+        # attached only for the headline workload it was measured on, and labelled with its source; otherwise null.
+        traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and (args.scene, args.width, args.spp, world) == (6, 1920, 4000, 1):
             try:
-                traffic = json.load(open(pmc_path)).get("k_extend" if ms_ext >= ms_sh else "k_shade", {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get("k_extend" if ms_ext >= ms_sh else "k_shade", {}).get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/pmc_latest.json ({pmc.get('source', 'earlier rocprofv3 --pmc passes of this command')}), not measured in this run"
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel": kname,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(kn),
                     "algorithmic_bytes_per_launch": round(bytes_total / max(kn, 1), 1),
                     "other_kernel": {"name": sh_name if ms_ext >= ms_sh else ext_name,
@@ -191,19 +196,21 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"scene {args.scene} ({SCENE_NOTE.get(args.scene, 'reference main.rs scene script')}) {args.width}x{height} @ {args.spp} spp, max_depth 50, seed {args.seed}",
-                       "parallelism": f"spp-sharded x{world}, one RCCL reduce of the f64 W*H*3 accumulator" if world > 1 else "single GPU",
+                       "parallelism": f"spp-sharded x{world}, one ncclReduce (RCCL, called by libpt_amd.so) of the f64 W*H*3 device accumulator" if world > 1 else "single GPU (1-rank communicator, no collective)",
                        "slots_per_pixel": stats[0]["slots_per_pixel"], "resident_paths": stats[0]["n_slots"],
                        "segments_per_sample": round(total_segments / max(total_samples, 1), 4), "scene_build_s": round(build_s, 3),
                        "device": ctx.name()},
             "roofline": roofline,
         }
+        out["frame_check"] = frame_check(pt, ctx, args, acc, height)
         if world == 1 and not args.no_cpu_baseline:
             images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt._SCENE_IMAGES.get(args.scene, [])}
             out["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.cpu_seconds, images)
             out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+    scene.close()
+    comm.close()
+    ctx.close()
 
 
 if __name__ == "__main__":

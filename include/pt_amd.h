@@ -53,7 +53,7 @@ typedef struct pt_render_stats {
     double ms_total;                       /* wall time inside pt_render (host clock, synced) */
     double ms_extend, ms_shade, ms_other;  /* HIP-event time per kernel family (profile=1) */
     uint64_t launches_extend, launches_shade;
-    uint32_t extend_variant, shade_variant;   /* K2: 0 two-phase k_extend2, 1 batch k_extend, 2 dynamic-fetch; K3: sort*10 + min waves/SIMD */
+    uint32_t extend_variant, shade_variant;   /* K2: 0 two-phase k_extend2, 1 batch k_extend; K3: sort*10 + min waves/SIMD */
     uint32_t blocks_extend, blocks_shade;
 } pt_render_stats;
 
@@ -124,6 +124,29 @@ int pt_render(pt_scene*, const pt_camera*, uint64_t seed, uint32_t spp_begin, ui
               const pt_render_opts* opts, pt_render_stats* stats);
 /* camera.rs:109-114,128-130: mean, sqrt gamma, clamp(0,0.999)*256 as u8. Host buffers. */
 int pt_resolve_u8(pt_ctx*, const double* accum, uint32_t n_pixels, uint32_t total_spp, uint8_t* rgb8);
+
+/* ---- multi-GPU: one process per GPU, spp sharding, ONE RCCL reduce over xGMI --------------------------------------
+ * The reference is a single process (rayon over pixels, camera.rs:102); samples of a pixel are only summed
+ * (camera.rs:106-108), so rank r of N renders the sample range pt_shard_range(spp, r, N) of every pixel and one
+ * ncclReduce(sum, f64, root 0) of the W*H*3 sample SUMS lands the frame on rank 0. RCCL is called directly from
+ * /opt/rocm on the device accumulator, on the render stream: no torch, no host bounce. */
+typedef struct pt_comm pt_comm;       /* one rank of an RCCL communicator, bound to a pt_ctx's device and stream */
+void pt_shard_range(uint32_t spp, int rank, int world, uint32_t* lo, uint32_t* hi);   /* contiguous, disjoint, near-equal */
+/* Rendezvous of the `world` processes of one launch (rank / world as torchrun's RANK / WORLD_SIZE): rank 0 creates the
+ * RCCL unique id and publishes it in the file `id_path` (any path all ranks agree on and no earlier launch used), the
+ * others wait for it up to timeout_s (<= 0: 120 s); then ncclCommInitRank. world == 1 needs no file. */
+int pt_comm_create(pt_ctx*, int rank, int world, const char* id_path, double timeout_s, pt_comm** out);
+void pt_comm_destroy(pt_comm*);
+int pt_comm_rank(pt_comm*);
+int pt_comm_world(pt_comm*);
+int pt_comm_barrier(pt_comm*);        /* all ranks have arrived and every device is idle */
+int pt_comm_allreduce_f64(pt_comm*, double* host_values, uint32_t n /* <= 64 */, int op /* 0 sum, 1 max */);
+int pt_bootstrap_exchange(const char* path, int rank, void* bytes, uint32_t n, double timeout_s);   /* the file rendezvous itself (host only) */
+/* Camera::render on all ranks of the communicator: samples [0, spp_total) split by pt_shard_range, rendered into a
+ * device accumulator, reduced onto rank 0 and ADDED there to accum_root (host, W*H*3 sums; ignored on other ranks).
+ * stats are this rank's. */
+int pt_render_multi(pt_scene*, const pt_camera*, uint64_t seed, uint32_t spp_total, pt_comm*, double* accum_root,
+                    const pt_render_opts* opts, pt_render_stats* stats);
 
 /* ---- parity probes (tests only) ---------------------------------------------------------- */
 /* closest hit of n rays {o.xyz, d.xyz, time} against the built world (World::intersect_all,

@@ -418,9 +418,51 @@ PT_DM double exp(double x) {
     y = dm_words(dm_hi(y) + (int32_t)((uint32_t)(k + 1000) << 20), dm_lo(y));
     return y * twom1000;
 }
-// x > 0 only (the renderer's single use: GTR1 sampling, sampling.rs:132)
+// 2^(th + tl) for |th| < 1000, rounded once: e^r = 1 + r + r^2/2 + r^3 E(r) with r = (th - n) ln2 in double-double
+// (E: degree-11 Chebyshev fit at 120 digits, tools/make_detmath_coeffs.py).
+PT_DM double dm_exp2_dd(double th, double tl) {
+    const double LN2H = 0x1.62e42fefa39efp-1, LN2L = 0x1.abc9e3b39803fp-56;
+    const double E0 = 0x1.5555555555555p-3, E1 = 0x1.5555555555555p-5, E2 = 0x1.1111111111111p-7, E3 = 0x1.6c16c16c16c17p-10,
+                 E4 = 0x1.a01a01a0196aep-13, E5 = 0x1.a01a01a019b64p-16, E6 = 0x1.71de3a5aa6f3ap-19, E7 = 0x1.27e4fb7a271ecp-22,
+                 E8 = 0x1.ae642c871071fp-26, E9 = 0x1.1eed7a04130cdp-29, E10 = 0x1.61bfa26897079p-33, E11 = 0x1.94328811e7eb4p-37;
+    const double fn = (double)(int64_t)(th + (th < 0.0 ? -0.5 : 0.5));
+    const double f = th - fn;                                 // exact, |f| <= 1/2
+    const double rh = f * LN2H;
+    const double rl = dm_fma(f, LN2H, -rh) + (f * LN2L + tl * LN2H);
+    double e = dm_fma(E11, rh, E10);
+    e = dm_fma(e, rh, E9);
+    e = dm_fma(e, rh, E8);
+    e = dm_fma(e, rh, E7);
+    e = dm_fma(e, rh, E6);
+    e = dm_fma(e, rh, E5);
+    e = dm_fma(e, rh, E4);
+    e = dm_fma(e, rh, E3);
+    e = dm_fma(e, rh, E2);
+    e = dm_fma(e, rh, E1);
+    e = dm_fma(e, rh, E0);
+    const double ah = rh * rh;
+    const double al = dm_fma(rh, rh, -ah) + (2.0 * rh) * rl;  // r^2 = ah + al
+    const double s3 = (ah * rh) * e;
+    const double uh = 1.0 + rh;
+    const double ul = (1.0 - uh) + rh;                        // Fast2Sum, 1 >= |rh|
+    const double s2h = 0.5 * ah;
+    const double vh = uh + s2h;
+    const double vl = (uh - vh) + s2h;                        // Fast2Sum, uh >= 0.65 > s2h
+    const double m = vh + (vl + (ul + (rl + (0.5 * al + s3))));
+    return dm_words(dm_hi(m) + (int32_t)((uint32_t)(int32_t)fn << 20), dm_lo(m));   // m in [0.70, 1.42]: the result stays normal
+}
+// x > 0 only (the renderer's single use: GTR1 sampling, pow(0.25^2, 1 - e1), sampling.rs:132). A base that is an exact
+// power of two — the renderer's always is — goes through the once-rounded exp2 above (the direction it yields is sampled,
+// so every last-bit difference from libm can flip a checker cell at the next hit); other bases through exp(y log x).
 PT_DM double pow(double x, double y) {
     if (!(x > 0.0)) return dm_nan();
+    const uint64_t bx = dm_bits(x);
+    const int32_t ex = (int32_t)((bx >> 52) & 0x7ff);
+    if ((bx & 0x000FFFFFFFFFFFFFull) == 0 && ex != 0 && ex != 0x7ff) {
+        const double k = (double)(ex - 1023);
+        const double th = k * y;
+        if (dm_abs(th) < 1000.0) return dm_exp2_dd(th, dm_fma(k, y, -th));
+    }
     return exp(y * log(x));
 }
 

@@ -1,12 +1,16 @@
-"""N>1 path on CPU: spp sharding + one reduce of the per-rank SUM accumulators to rank 0
-(gloo, world_size 2). The renderer behind the shard is the CPU oracle here (no GPU in this
-container); the sharding / reduce / resolve code is the same module bench.py uses on GPUs."""
+"""N>1 path on CPU (world_size 2, gloo standing in for RCCL — there is no GPU in this container).
+
+What runs here is the host logic of the product's multi-GPU entry point, through the C ABI: pt_shard_range (which
+samples a rank renders) and pt_bootstrap_exchange (the file rendezvous pt_comm_create uses to hand the RCCL unique id
+from rank 0 to the others). The renderer behind the shard is the CPU oracle and the sum of the per-rank SUM
+accumulators is a gloo reduce — on GPUs those two are pt_render and ncclReduce inside pt_render_multi (csrc/pt_comm.cpp;
+its 1-rank form is tested on the GPU in test_gpu_parity.py)."""
+import importlib
 import os
 import socket
 import sys
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -22,19 +26,23 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, spp, out_path):
+def _worker(rank, world, port, spp, out_path, id_path):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as orc
-    import parallel_spp
+    pt = importlib.import_module("thu-acg-f2024-path-tracer_amd")
 
+    # the rendezvous of pt_comm_create: rank 0 publishes 128 bytes (a stand-in for the ncclUniqueId), the others wait for them
+    token = bytes(range(128)) if rank == 0 else bytes(128)
+    got = pt.bootstrap_exchange(id_path, rank, token, 30.0)
+    assert got == bytes(range(128))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     s = orc.Scene()
     cam = s.build_scene(3, 24, spp)
-    lo, hi = parallel_spp.shard_range(spp, rank, world)
+    lo, hi = pt.shard_range(spp, rank, world)
     acc, cnt = s.render(cam, 1, lo, hi)
     t = torch.from_numpy(acc)
-    parallel_spp.reduce_accum_to_root(t)                 # ONE collective: sum of the sample SUMS
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)          # ONE collective: sum of the sample SUMS (ncclReduce on GPUs)
     seg = torch.tensor([cnt["segments"], hi - lo], dtype=torch.int64)
     dist.all_reduce(seg)
     if rank == 0:
@@ -42,23 +50,28 @@ def _worker(rank, world, port, spp, out_path):
     dist.destroy_process_group()
 
 
-def test_shard_range_covers_everything():
-    import parallel_spp
-
+def test_shard_range_covers_everything(pt):
     for spp in (0, 1, 7, 4000):
         for world in (1, 2, 3, 8):
-            parts = [parallel_spp.shard_range(spp, r, world) for r in range(world)]
+            parts = [pt.shard_range(spp, r, world) for r in range(world)]
             assert parts[0][0] == 0 and parts[-1][1] == spp
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
-    assert [parallel_spp.shard_range(4000, r, 8) for r in range(8)][3] == (1500, 2000)
+    assert [pt.shard_range(4000, r, 8) for r in range(8)][3] == (1500, 2000)
+
+
+def test_bootstrap_exchange_times_out_without_a_publisher(pt, tmp_path):
+    import pytest
+
+    with pytest.raises(pt.PtError, match="timed out"):
+        pt.bootstrap_exchange(str(tmp_path / "nobody"), 1, bytes(8), 0.2)
 
 
 def test_two_rank_render_equals_single_process(orc, tmp_path):
     spp = 6
     out = str(tmp_path / "r.npz")
-    mp.spawn(_worker, args=(2, _free_port(), spp, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), spp, out, str(tmp_path / "rccl_id")), nprocs=2, join=True)
     got = np.load(out)
     s = orc.Scene()
     cam = s.build_scene(3, 24, spp)

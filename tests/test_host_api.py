@@ -24,9 +24,11 @@ def test_library_exports_every_declared_symbol(pt):
 
 
 def test_no_torch_and_no_oracle_in_the_product(pt):
-    """The boundary is plain C; the product must not link or import the oracle (or torch)."""
+    """The boundary is plain C; the product must not link or import the oracle (or torch). Its only GPU-side
+    dependencies are the HIP runtime and RCCL, both from /opt/rocm."""
     out = subprocess.run(["ldd", pt.LIB_PATH], capture_output=True, text=True).stdout
-    assert "liboracle" not in out and "torch" not in out and "libamdhip64" in out
+    assert "liboracle" not in out and "torch" not in out and "libamdhip64" in out and "librccl" in out
+    assert not re.search(r"^\s*(import|from)\s+torch", open(os.path.join(ROOT, "bench.py")).read(), flags=re.M)   # bench.py drives RCCL through the C ABI
     src_dir = os.path.join(ROOT, "thu-acg-f2024-path-tracer_amd")
     for dp, _, files in os.walk(src_dir):
         for f in files:

@@ -93,6 +93,8 @@ ABI_SYMBOLS = [
     "pt_world_add_object", "pt_world_add_light", "pt_world_build", "pt_world_prim_count",
     "pt_load_obj", "pt_load_hdr_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
     "pt_build_scene", "pt_camera_init", "pt_render", "pt_resolve_u8", "pt_intersect", "pt_math_probe",
+    "pt_shard_range", "pt_comm_create", "pt_comm_destroy", "pt_comm_rank", "pt_comm_world", "pt_comm_barrier", "pt_comm_allreduce_f64",
+    "pt_bootstrap_exchange", "pt_render_multi",
 ]
 
 
@@ -152,6 +154,18 @@ def _load():
     lib.pt_load_hdr_rgb8.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pt_free.argtypes = [C.c_void_p]
     lib.pt_free.restype = None
+    lib.pt_shard_range.argtypes = [C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.pt_shard_range.restype = None
+    lib.pt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_double, C.POINTER(C.c_void_p)]
+    lib.pt_comm_destroy.argtypes = [C.c_void_p]
+    lib.pt_comm_destroy.restype = None
+    lib.pt_comm_rank.argtypes = [C.c_void_p]
+    lib.pt_comm_world.argtypes = [C.c_void_p]
+    lib.pt_comm_barrier.argtypes = [C.c_void_p]
+    lib.pt_comm_allreduce_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    lib.pt_bootstrap_exchange.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_uint32, C.c_double]
+    lib.pt_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.POINTER(RenderOpts), C.POINTER(RenderStats)]
     return lib
 
 
@@ -205,6 +219,42 @@ class Context:
         out = np.empty(accum.shape, dtype=np.uint8)
         _check(lib.pt_resolve_u8(self.handle, accum.ctypes.data, accum.size // 3, total_spp, out.ctypes.data), "pt_resolve_u8")
         return out
+
+
+def shard_range(spp: int, rank: int, world: int):
+    """Sample range [lo, hi) that rank `rank` of `world` renders (pt_shard_range)."""
+    lo, hi = C.c_uint32(), C.c_uint32()
+    lib.pt_shard_range(spp, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def bootstrap_exchange(path: str, rank: int, payload: bytes, timeout_s: float = 60.0) -> bytes:
+    """The file rendezvous pt_comm_create uses for the RCCL unique id: rank 0 publishes `payload`, the others get it."""
+    buf = C.create_string_buffer(payload, len(payload))
+    _check(lib.pt_bootstrap_exchange(path.encode(), rank, buf, len(payload), timeout_s), "pt_bootstrap_exchange")
+    return buf.raw
+
+
+class Comm:
+    """One rank of an RCCL communicator over the GPUs of a node (one process per GPU)."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, id_path: Optional[str] = None, timeout_s: float = 120.0):
+        h = C.c_void_p()
+        _check(lib.pt_comm_create(ctx.handle, rank, world, None if id_path is None else id_path.encode(), timeout_s, C.byref(h)), "pt_comm_create")
+        self.handle, self.ctx, self.rank, self.world = h, ctx, rank, world
+
+    def close(self):
+        if self.handle:
+            lib.pt_comm_destroy(self.handle)
+            self.handle = None
+
+    def barrier(self):
+        _check(lib.pt_comm_barrier(self.handle), "pt_comm_barrier")
+
+    def allreduce(self, values, op: str = "sum") -> np.ndarray:
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        _check(lib.pt_comm_allreduce_f64(self.handle, v.ctypes.data, v.size, 1 if op == "max" else 0), "pt_comm_allreduce_f64")
+        return v
 
 
 class Scene:
@@ -300,6 +350,21 @@ class Scene:
             ptr = C.c_void_p(accum.ctypes.data)
         _check(lib.pt_render(self.handle, C.byref(cam), seed, spp_begin, spp_end, ptr, C.byref(opts), C.byref(stats)), "pt_render")
         return accum, stats
+
+    def render_multi(self, cam: Camera, seed: int, spp_total: int, comm: Comm, accum=None, slots_per_pixel: int = 0, profile: bool = False):
+        """Camera::render over all ranks of `comm` (pt_render_multi): spp sharding + one RCCL reduce onto rank 0.
+        Returns (accum on rank 0 / None elsewhere, this rank's stats)."""
+        h = image_height(cam)
+        opts = RenderOpts(slots_per_pixel, 0, 1 if profile else 0, 0, None)
+        stats = RenderStats()
+        ptr = None
+        if comm.rank == 0:
+            if accum is None:
+                accum = np.zeros((h, cam.image_width, 3), dtype=np.float64)
+            assert accum.dtype == np.float64 and accum.flags["C_CONTIGUOUS"] and accum.size == h * cam.image_width * 3
+            ptr = C.c_void_p(accum.ctypes.data)
+        _check(lib.pt_render_multi(self.handle, C.byref(cam), seed, spp_total, comm.handle, ptr, C.byref(opts), C.byref(stats)), "pt_render_multi")
+        return (accum if comm.rank == 0 else None), stats
 
     def intersect(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)

@@ -112,8 +112,8 @@ PT_DEV V3 cosine_sample_hemisphere(Rng& rng, double two_pi_scale) {   // samplin
     double phi = ((double)(a >> 12) * (1.0 / 4503599627370496.0)) * two_pi_scale;
     double r2 = u64_to_unit(b);
     double r2s = sqrt(r2);
-    double sn, cs;
-    detmath::sincos(phi, sn, cs);
+    const SinCos sc_phi = dev_sincos(phi);
+    const double sn = sc_phi.s, cs = sc_phi.c;
     return V3{r2s * cs, r2s * sn, sqrt(1.0 - r2)};
 }
 PT_DEV V3 ggx_sample_microfacet_normal(V3 v_in, double roughness, Rng& rng) {   // sampling.rs:57-94
@@ -127,8 +127,8 @@ PT_DEV V3 ggx_sample_microfacet_normal(V3 v_in, double roughness, Rng& rng) {   
     double a = 1.0 / (1.0 + v.z);
     double r = sqrt(e1);
     double phi = e2 < a ? e2 / a * D_PI : D_PI + (e2 - a) / (1.0 - a) * D_PI;
-    double sn, cs;
-    detmath::sincos(phi, sn, cs);
+    const SinCos sc_phi = dev_sincos(phi);
+    const double sn = sc_phi.s, cs = sc_phi.c;
     double p1 = r * cs;
     double p2 = r * sn * (e2 < a ? 1.0 : v.z);
     V3 n = p1 * t1 + p2 * t2 + sqrt(fmax(1.0 - p1 * p1 - p2 * p2, 0.0)) * v;
@@ -143,8 +143,8 @@ PT_DEV V3 gtr1_sample_microfacet_normal(double alpha, Rng& rng) {   // sampling.
     double cos_theta = (1.0 - detmath::pow(alpha2, 1.0 - e1)) / (1.0 - alpha2);
     double sin_theta = sqrt(fmax(1.0 - cos_theta * cos_theta, 0.0));
     double phi = 2.0 * D_PI * e2;
-    double sn, cs;
-    detmath::sincos(phi, sn, cs);
+    const SinCos sc_phi = dev_sincos(phi);
+    const double sn = sc_phi.s, cs = sc_phi.c;
     V3 h{sin_theta * cs, sin_theta * sn, cos_theta};
     return h.z < 0.0 ? -h : h;
 }

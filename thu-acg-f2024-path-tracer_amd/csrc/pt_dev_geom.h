@@ -108,8 +108,8 @@ PT_DEV bool reconstruct_hit(const SceneD& sc, const RayD& world_ray, uint32_t gi
         if (!hit_sphere(sc.spheres[pr.index], r, t_min, t, c)) return false;
         V3 point = ray_at(r, t);
         V3 normal = normalize(point - c);
-        double theta = detmath::acos(-normal.y);                       // sphere.rs:52-56
-        double phi = detmath::atan2(-normal.z, normal.x) + D_PI;
+        double theta = dev_acos(-normal.y);                       // sphere.rs:52-56
+        double phi = dev_atan2(-normal.z, normal.x) + D_PI;
         finish_hit(sc, r, point, normal, t, pr.mat, phi / (2.0 * D_PI), theta / D_PI, h);
     } else if (kind == PRIM_QUAD) {
         double t, a, b;
@@ -188,10 +188,9 @@ PT_DEV V3 lights_sample(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
         const SphereD& s = sc.spheres[sc.prims[e.first_prim].index];
         double a = rng_f64(rng), b = rng_f64(rng);
         double theta = 2.0 * D_PI * a;
-        double phi = detmath::acos(2.0 * b - 1.0);
-        double sp, cp, st, ct;
-        detmath::sincos(phi, sp, cp);
-        detmath::sincos(theta, st, ct);
+        double phi = dev_acos(2.0 * b - 1.0);
+        const SinCos scp = dev_sincos(phi), sct = dev_sincos(theta);
+        const double sp = scp.s, cp = scp.c, st = sct.s, ct = sct.c;
         V3 center = ld3(s.p1) + (ld3(s.p2) - ld3(s.p1)) * time;
         V3 point = center + V3{sp * ct, sp * st, cp} * s.r;
         dir = normalize(point - origin);
@@ -282,8 +281,8 @@ PT_DEV void random_offsets(Rng& rng, double& ox, double& oy) {
     rng_u64x2(rng, a, b);
     double radius = sqrt(u64_to_unit(a));
     double angle = u64_to_unit(b) * 2.0 * D_PI;
-    double sn, cs;
-    detmath::sincos(angle, sn, cs);
+    const SinCos sc_angle = dev_sincos(angle);
+    const double sn = sc_angle.s, cs = sc_angle.c;
     ox = radius * cs;
     oy = radius * sn;
 }
@@ -302,8 +301,8 @@ PT_DEV RayD generate_ray(const CamD& cam, uint32_t row, uint32_t col, Rng& rng) 
 // camera.rs:140-151
 PT_DEV V3 sample_environment(const SceneD& sc, const CamD& cam, V3 d) {
     if (!cam.env_is_map) return ld3(cam.env_color);
-    double theta = detmath::acos(d.y);
-    double phi = detmath::atan2(d.z, d.x);
+    double theta = dev_acos(d.y);
+    double phi = dev_atan2(d.z, d.x);
     double u = (phi + D_PI) / (2.0 * D_PI);
     double v = 1.0 - theta / D_PI;
     return tex_image(sc, ldu(&sc.tex[cam.env_tex]), u, v);   // the environment's descriptor is the same for every lane

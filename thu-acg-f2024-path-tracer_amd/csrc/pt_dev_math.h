@@ -66,6 +66,26 @@ PT_DEV V3 refract(V3 i, V3 n, double eta) {
 }
 PT_DEV double luminance(V3 c) { return 0.2126 * c.x + 0.7152 * c.y + 0.0722 * c.z; }
 
+// Elementary functions as real (non-inlined) device functions: k_shade calls sincos at ten sites and acos/atan2 at four;
+// inlined, each copy brings its ~40 registers of temporaries to a spot that is already at the kernel's 256-register limit
+// (the round-2 sin/cos kernels carry double-double terms) and the compiler spilled 300 B per lane. One shared body keeps
+// the callers' allocation where it was and shrinks the kernel's code by a third.
+struct SinCos {
+    double s, c;
+};
+#ifndef PT_DETMATH_INLINE
+#define PT_DM_CALL __device__ __noinline__
+#else
+#define PT_DM_CALL __device__ __forceinline__
+#endif
+PT_DM_CALL SinCos dev_sincos(double x) {
+    SinCos r;
+    detmath::sincos(x, r.s, r.c);
+    return r;
+}
+PT_DM_CALL double dev_acos(double x) { return detmath::acos(x); }
+PT_DM_CALL double dev_atan2(double y, double x) { return detmath::atan2(y, x); }
+
 // Wave-uniform read of read-only scene data. The kernels also STORE to global memory (the path pool), so the compiler
 // cannot prove that a plain load with a uniform address is never clobbered and issues a vector load for it: every lane
 // fetches the same bytes into VGPRs. Read through the constant address space the same access becomes a scalar load

@@ -6,16 +6,15 @@
 
 namespace pt {
 void launch_init(const CamD& cam, const PoolD& pool, uint64_t seed, int max_blocks, hipStream_t st);
-void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int fetch_threshold, hipStream_t st);
+void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int code, hipStream_t st);
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
                   hipStream_t st);
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st);
 void launch_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8, hipStream_t st);
-void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, int variant, hipStream_t st);
+void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, hipStream_t st);
 void launch_math_probe(int which, const double* in, uint32_t n, double* out, hipStream_t st);
-// K2 variant code (`fetch_threshold` of launch_extend / kernel_occupancy_blocks): -1 = batch kernel (-2 asks
-// kernel_occupancy_blocks for its flat-top-level instantiation),
-// 1..64 = dynamic-fetch kernel with that refill threshold, -(stack*10 + blocks) = two-phase kernel
+// K2 variant code (`code` of launch_extend / `variant` of kernel_occupancy_blocks): -1 = batch kernel (-2 asks
+// kernel_occupancy_blocks for its flat-top-level instantiation), -(stack*10 + blocks) = two-phase kernel
 // k_extend2<stack, blocks> for stack in {16, 20, 24}.
 int kernel_occupancy_blocks(int which, int variant);   // 0 = extend, 1 = shade; resident blocks per CU
 }  // namespace pt

@@ -2,7 +2,7 @@
 //
 //   k_init     K1 raygen       camera.rs:153-168  fills the pool with the first sample of every slot
 //   k_extend2  K2 closest hit  world.rs:47-62 -> bvh.rs:123-164 -> sphere/quad/mesh/instance.rs  (two-phase form; k_extend =
-//                              batch form for scenes without meshes, k_extend_fetch = experimental dynamic-fetch form)
+//                              batch form for scenes without meshes)
 //   k_shade    K3+K4+K1'       camera.rs:177-226 body: miss/env, emission, RR, one-sample MIS,
 //                              BSDF sample+pdf+eval, next ray; finished paths are regenerated in place
 //   k_resolve  K6 (sum part)   camera.rs:106-109: per-pixel sum of the slot accumulators
@@ -123,16 +123,6 @@ PT_DEV bool slab_f32(const float* lo, const float* hi, const RayF& f, float t_mi
     t_near = tn;
     return tn <= tf;
 }
-// f64 reference slab test (aabb.rs:31-42 arithmetic on the padded boxes); kept for A/B debugging
-PT_DEV bool slab_f64(const float* lo, const float* hi, V3 o, V3 inv, double t_min, double t_max, double& t_near) {
-    double t1x = ((double)lo[0] - o.x) * inv.x, t2x = ((double)hi[0] - o.x) * inv.x;
-    double t1y = ((double)lo[1] - o.y) * inv.y, t2y = ((double)hi[1] - o.y) * inv.y;
-    double t1z = ((double)lo[2] - o.z) * inv.z, t2z = ((double)hi[2] - o.z) * inv.z;
-    double tn = fmax(fmax(fmin(t1x, t2x), fmin(t1y, t2y)), fmax(fmin(t1z, t2z), t_min));
-    double tf = fmin(fmin(fmax(t1x, t2x), fmax(t1y, t2y)), fmin(fmax(t1z, t2z), t_max));
-    t_near = tn;
-    return tn <= tf;
-}
 // one BVH2 node: both children tested, near-first order; returns the number of children to visit
 PT_DEV int visit_node(const BvhNode* nd, const RayF& f, float t_min, float t_max, uint32_t& first, uint32_t& second) {
     const float4 q0 = ((const float4*)nd)[0], q1 = ((const float4*)nd)[1], q2 = ((const float4*)nd)[2];
@@ -175,13 +165,11 @@ PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint3
 }
 struct Box6 { float lo[3], hi[3]; };   // SceneD::entry_box record
 
-template <bool F32>
 PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uint32_t* stk /* &stack[0][lane] */) {
     Closest best{D_INF, HIT_NONE};
     RayD r = wray;
     const RayF fw = make_rayf(wray.o, wray.d, sc.tlas_extent);   // world-space reduction, kept across instances
     RayF f = fw;
-    V3 inv{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};   // f64 variant only
     const float t_min_f = __double2float_rd(t_min);
     float t_max_f = t_max_f32(best.t);
     int sp = 0;
@@ -190,18 +178,7 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
         if ((cur & REF_TYPE_MASK) == REF_NODE) {
             const BvhNode* nd = &sc.nodes[cur];
             uint32_t c0, c1;
-            int n;
-            if (F32) {
-                n = visit_node(nd, f, t_min_f, t_max_f, c0, c1);
-            } else {
-                double tn0, tn1;
-                const bool h0 = slab_f64(nd->lo0, nd->hi0, r.o, inv, t_min, best.t, tn0);
-                const bool h1 = slab_f64(nd->lo1, nd->hi1, r.o, inv, t_min, best.t, tn1);
-                const bool swap = h0 && h1 && tn1 < tn0;
-                c0 = (h0 && !swap) ? nd->child0 : nd->child1;
-                c1 = swap ? nd->child0 : nd->child1;
-                n = (h0 ? 1 : 0) + (h1 ? 1 : 0);
-            }
+            const int n = visit_node(nd, f, t_min_f, t_max_f, c0, c1);
             if (n == 2 && sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = c1;
             if (n > 0) {
                 cur = c0;
@@ -221,7 +198,6 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
             if (e.kind == ENTRY_MESH) {
                 r = lr;
                 f = make_rayf(r.o, r.d, e.extent);
-                if (!F32) inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
                 if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = REF_LEAVE_INSTANCE;
                 cur = e.blas_root;
                 continue;
@@ -232,7 +208,6 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
         } else if (cur == REF_LEAVE_INSTANCE) {
             r = wray;
             f = fw;
-            if (!F32) inv = V3{1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
         }
         if (sp == 0) break;
         cur = stk[(--sp) * BLOCK];
@@ -333,7 +308,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
         if (alive) r = load_ray(pool, s);
         Closest c{D_INF, HIT_NONE};
         if (FLAT) c = closest_hit_flat(sc, alive, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
-        else if (alive) c = closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]);
+        else if (alive) c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);
         if (alive) {
             stnt(&pool.hit_prim[s], (uint32_t)(c.id));
             ++nseg;
@@ -602,110 +577,6 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
             stnt(&pool.hit_prim[wbase + sl], s_best_id[sl]);
         }
         __syncthreads();   // LDS lists are reused by the next window
-    }
-    if (nseg) atomicAdd(&cnt->segments, nseg);
-}
-
-// K2 as a persistent-thread kernel with DYNAMIC RAY FETCH (Aila-Laine style): traversal lengths
-// vary by two orders of magnitude between a sky ray and a ray grazing a mesh, so a lane that
-// finishes its ray does not wait for the slowest lane of its wave — whenever enough lanes of the
-// wave are idle, the idle lanes pull the next slots from a per-launch cursor (ballot + popcount +
-// one atomic per wave) and start traversing them while the others continue. Each loop iteration
-// performs ONE traversal step (node visit / triangle leaf / world entry / pop) per active lane.
-__global__ __launch_bounds__(BLOCK) void k_extend_fetch(SceneD sc, PoolD pool, CountersD* cnt, int fetch_threshold) {
-    __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
-    uint32_t* stk = &stack[threadIdx.x];
-    const int lane = (int)(threadIdx.x & 63u);
-    const double t_min = 1e-3;                                    // camera.rs:171,179
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
-
-    // this wave's contiguous share of the pool (multiples of 64 slots); refills walk it with a
-    // wave-uniform cursor — no atomics
-    const uint32_t n_waves = gridDim.x * (BLOCK / 64), gw = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const uint32_t per_wave = ((pool.n_alloc / 64 + n_waves - 1) / n_waves) * 64;
-    uint32_t cursor = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((unsigned long long)gw * per_wave, (unsigned long long)pool.n_alloc));
-    const uint32_t cursor_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((unsigned long long)cursor + per_wave, (unsigned long long)pool.n_alloc));
-    bool active = false, exhausted = cursor >= cursor_end;
-    uint32_t slot = 0, cur = 0;
-    int sp = 0;
-    RayD r{};          // ray in the current space (world, or instance-local inside a mesh)
-    RayF f{};          // its f32 reduction for the box tests
-    const float t_min_f = __double2float_rd(t_min);
-    float t_max_f = 0.0f;
-    Closest best{D_INF, HIT_NONE};
-    unsigned long long nseg = 0;
-
-    for (;;) {
-        // ---- refill idle lanes ---------------------------------------------------------------
-        const unsigned long long idle = __ballot(!active);
-        if (!exhausted && (idle == ~0ull || __popcll(idle) >= fetch_threshold)) {
-            const uint32_t base = cursor;
-            cursor += (uint32_t)__popcll(idle);                   // wave-uniform
-            if (cursor >= cursor_end) exhausted = true;
-            if (!active) {
-                const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (idx < cursor_end && pool.bounce[idx] < SLOT_IDLE) {
-                    slot = (uint32_t)idx;
-                    r = load_ray(pool, slot);
-                    f = make_rayf(r.o, r.d, sc.tlas_extent);
-                    best = Closest{D_INF, HIT_NONE};
-                    t_max_f = t_max_f32(best.t);
-                    sp = 0;
-                    cur = sc.tlas_root;
-                    active = true;
-                    ++nseg;
-                }
-            }
-        }
-        if (__ballot(active) == 0ull) {
-            if (exhausted) break;
-            continue;
-        }
-        if (!active) continue;
-        // ---- one traversal step ----------------------------------------------------------------
-        bool pop = true;
-        if ((cur & REF_TYPE_MASK) == REF_NODE) {
-            uint32_t c0, c1;
-            const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
-            if (n == 2 && sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = c1;
-            if (n > 0) {
-                cur = c0;
-                pop = false;
-            }
-        } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
-            const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
-            for (uint32_t i = first; i < first + count; ++i) {
-                double t, u, v;
-                if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
-            }
-            t_max_f = t_max_f32(best.t);
-        } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
-            const Entry e = sc.entries[cur & 0x3FFFFFFFu];
-            RayD lr = r;                                          // world space here (entries live in the TLAS)
-            if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], r);
-            if (e.kind == ENTRY_MESH) {
-                r = lr;
-                f = make_rayf(r.o, r.d, e.extent);
-                if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = REF_LEAVE_INSTANCE;
-                cur = e.blas_root;
-                pop = false;
-            } else {
-                const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
-                for (uint32_t i = 0; i < n; ++i) test_world_prim(sc, lr, t_min, e.first_prim + i, best);
-                t_max_f = t_max_f32(best.t);
-            }
-        } else if (cur == REF_LEAVE_INSTANCE) {                   // back to world space: reload the ray
-            r = load_ray(pool, slot);
-            f = make_rayf(r.o, r.d, sc.tlas_extent);
-        }
-        if (pop) {
-            if (sp == 0) {
-                stnt(&pool.hit_prim[slot], (uint32_t)(best.id));
-                active = false;
-            } else {
-                cur = stk[(--sp) * BLOCK];
-            }
-        }
     }
     if (nseg) atomicAdd(&cnt->segments, nseg);
 }
@@ -987,12 +858,12 @@ __global__ __launch_bounds__(BLOCK) void k_quantise(const double* accum, uint32_
 
 // Debug/parity probe: closest hit + reconstructed HitInfo for a batch of arbitrary rays.
 // out[15*i..] = {hit, t, prim_id, u, v, front, p.xyz, gn.xyz, sn.xyz}
-__global__ __launch_bounds__(BLOCK) void k_probe(SceneD sc, const double* rays /* o.xyz d.xyz time */, uint32_t n, double* out, int variant) {
+__global__ __launch_bounds__(BLOCK) void k_probe(SceneD sc, const double* rays /* o.xyz d.xyz time */, uint32_t n, double* out) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const double* q = rays + 7 * (size_t)i;
         RayD r = make_ray(V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, q[6]);
-        Closest c = variant ? closest_hit<true>(sc, r, 1e-3, &stack[threadIdx.x]) : closest_hit<false>(sc, r, 1e-3, &stack[threadIdx.x]);
+        Closest c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);
         double* o = out + 15 * (size_t)i;
         for (int j = 0; j < 15; ++j) o[j] = 0.0;
         HitD h;
@@ -1051,10 +922,9 @@ static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min 
     default: return k_extend2<24, 3>;
     }
 }
-void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int fetch_threshold, hipStream_t st) {
-    if (fetch_threshold <= -100) hipLaunchKernelGGL(pick_extend2(-fetch_threshold), grid_for((pool.n_alloc / EXT_WINDOW) * BLOCK, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
-    else if (fetch_threshold < 0) hipLaunchKernelGGL(sc.tlas_flat ? k_extend<true> : k_extend<false>, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
-    else hipLaunchKernelGGL(k_extend_fetch, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt, fetch_threshold);
+void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int code, hipStream_t st) {   // code: pt_render.cpp extend_code
+    if (code <= -100) hipLaunchKernelGGL(pick_extend2(-code), grid_for((pool.n_alloc / EXT_WINDOW) * BLOCK, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    else hipLaunchKernelGGL(sc.tlas_flat ? k_extend<true> : k_extend<false>, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
 }
 typedef void (*shade_fn)(SceneD, CamD, PoolD, CountersD*, uint64_t);
 static shade_fn pick_shade(int variant) {   // variant = sort*10 + min waves per SIMD
@@ -1077,15 +947,15 @@ void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_
 void launch_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8, hipStream_t st) {
     hipLaunchKernelGGL(k_quantise, grid_for(n, 4096), dim3(BLOCK), 0, st, accum, n, scale, rgb8);
 }
-void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, int variant, hipStream_t st) {
-    hipLaunchKernelGGL(k_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, sc, rays, n, out, variant);
+void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, sc, rays, n, out);
 }
 void launch_math_probe(int which, const double* in, uint32_t n, double* out, hipStream_t st) {
     hipLaunchKernelGGL(k_math_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, which, in, n, out);
 }
 int kernel_occupancy_blocks(int which, int variant) {
     int nb = 0;
-    const void* f = which == 0 ? (variant > 0 ? (const void*)k_extend_fetch : variant <= -100 ? (const void*)pick_extend2(-variant) : variant == -2 ? (const void*)k_extend<true> : (const void*)k_extend<false>) : (const void*)pick_shade(variant);
+    const void* f = which == 0 ? (variant <= -100 ? (const void*)pick_extend2(-variant) : variant == -2 ? (const void*)k_extend<true> : (const void*)k_extend<false>) : (const void*)pick_shade(variant);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

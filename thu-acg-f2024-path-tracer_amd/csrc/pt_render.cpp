@@ -198,7 +198,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     // counter. slots_per_pixel = k >= 1: STATIC ownership (deterministic; k = 1 is the reference's
     // exact per-pixel sample order).
     uint32_t k = opts.slots_per_pixel;
-    if (const char* e = getenv("PT_SLOTS_PER_PIXEL")) k = (uint32_t)atoi(e);
+    if (k == 0)   // an explicit option wins over the experiment switch
+        if (const char* e = exp_env("PT_SLOTS_PER_PIXEL")) k = (uint32_t)atoi(e);
     const bool dynamic = k == 0;
     const uint32_t tiles_x = (dc.width + 7) / 8, tiles_y = (dc.height + 7) / 8;
     const uint64_t n_tile_pixels64 = (uint64_t)tiles_x * tiles_y * 64;
@@ -213,7 +214,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         uint64_t per_cu = 16384;   // a power of two (the tile-ordered work items and the 64 counter shards divide it evenly)
         while (per_cu < 131072 && per_cu * 3 / 2 * (uint64_t)std::max(1, ctx->n_cus) * 128 <= total_work) per_cu *= 2;
         uint64_t target = (uint64_t)ctx->n_cus * per_cu;
-        if (const char* e = getenv("PT_POOL_SLOTS")) target = strtoull(e, nullptr, 10);
+        if (const char* e = exp_env("PT_POOL_SLOTS")) {
+            target = strtoull(e, nullptr, 10);
+            if (target == 0) return set_error("pt_render: PT_POOL_SLOTS must be positive");
+        }
         n_slots64 = std::min<uint64_t>(target, std::max<uint64_t>(total_work, 1));
     } else {
         if (k > spp) k = spp;
@@ -263,38 +267,43 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     pool.tiles_x = tiles_x;
     pool.n_tile_pixels = (uint32_t)n_tile_pixels64;
 
-    // accumulator on the device
+    // accumulator on the device (freed on every return path when it is ours)
     double* d_accum = accum;
     const size_t accum_bytes = (size_t)n_pixels * 3 * sizeof(double);
+    struct AccumGuard {
+        double* p = nullptr;
+        ~AccumGuard() { if (p) (void)hipFree(p); }
+    } own_accum;
     if (!opts.accum_on_device) {
         if (!hip_ok(hipMalloc((void**)&d_accum, accum_bytes), "hipMalloc(accum)")) return -1;
+        own_accum.p = d_accum;
         if (!hip_ok(hipMemsetAsync(d_accum, 0, accum_bytes, st), "hipMemset(accum)")) return -1;
     }
 
     // persistent grids: resident blocks per CU x CUs
     int mult = 1;
-    if (const char* e = getenv("PT_GRID_MULT")) mult = std::max(1, atoi(e));
+    if (const char* e = exp_env("PT_GRID_MULT")) mult = std::max(1, atoi(e));
     int shade_variant = 12;   // k_shade<sort, min waves/SIMD>: sort*10 + waves (12 = windowed material sort, 2 = plain)
-    if (const char* e = getenv("PT_SHADE_VARIANT")) shade_variant = atoi(e);
+    if (const char* e = exp_env("PT_SHADE_VARIANT")) shade_variant = atoi(e);
     // K2 variant: two-phase kernel when there are meshes to defer and its LDS stack covers the scene's BVHs, else the
-    // batch kernel. PT_FETCH_THRESHOLD overrides: 0 = two-phase, -1 = batch, n in 1..64 = dynamic-fetch kernel refilling a
-    // wave when >= n lanes are idle (experimental); PT_EXT2 = stack*10 + blocks per CU picks the instantiation.
+    // batch kernel. Experiment switches: PT_K2=batch forces the batch kernel; PT_EXT2 = stack*10 + blocks per CU picks
+    // the instantiation. extend_code: -1 = batch, -(stack*10 + blocks) = two-phase.
     auto extend2_code = [&]() -> int {
         const int need = (int)s->stack_need_extend2;
         if (need > 24) return 0;
         int code = need <= 16 ? 163 : need <= 20 ? 203 : 243;   // three blocks per CU: four would cap the kernel at 128 registers and spill
-        if (const char* e = getenv("PT_EXT2")) {
+        if (const char* e = exp_env("PT_EXT2")) {
             const int c = atoi(e);
             if (c / 10 >= need && (c == 163 || c == 203 || c == 242 || c == 243)) code = c;
         }
         return code;
     };
-    int fetch_threshold = (s->n_mesh_entries > 0 && extend2_code() != 0) ? -extend2_code() : -1;
-    if (const char* e = getenv("PT_FETCH_THRESHOLD")) {
-        const int v = std::min(64, std::max(-1, atoi(e)));
-        fetch_threshold = v == 0 ? (extend2_code() != 0 ? -extend2_code() : -1) : v;
+    int extend_code = (s->n_mesh_entries > 0 && extend2_code() != 0) ? -extend2_code() : -1;
+    if (const char* e = exp_env("PT_K2")) {
+        if (!strcmp(e, "batch")) extend_code = -1;
+        else if (!strcmp(e, "twophase") && extend2_code() != 0) extend_code = -extend2_code();
     }
-    const int blocks_extend = kernel_occupancy_blocks(0, fetch_threshold == -1 && s->dev.view.tlas_flat ? -2 : fetch_threshold), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
+    const int blocks_extend = kernel_occupancy_blocks(0, extend_code == -1 && s->dev.view.tlas_flat ? -2 : extend_code), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;
@@ -329,7 +338,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     while (alive) {
         for (uint32_t i = 0; i < poll_every; ++i) {
             timer.begin(0, st);
-            launch_extend(s->dev.view, pool, s->d_counters, grid_extend, fetch_threshold, st);
+            launch_extend(s->dev.view, pool, s->d_counters, grid_extend, extend_code, st);
             timer.end(st);
             timer.begin(1, st);
             launch_shade(s->dev.view, dc, pool, s->d_counters, seed, grid_shade, shade_variant, st);
@@ -356,9 +365,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
 
     if (!opts.accum_on_device) {
         std::vector<double> tmp((size_t)n_pixels * 3);
-        bool ok = hip_ok(hipMemcpy(tmp.data(), d_accum, accum_bytes, hipMemcpyDeviceToHost), "hipMemcpy(accum)");
-        (void)hipFree(d_accum);
-        if (!ok) return -1;
+        if (!hip_ok(hipMemcpy(tmp.data(), d_accum, accum_bytes, hipMemcpyDeviceToHost), "hipMemcpy(accum)")) return -1;
         for (size_t i = 0; i < tmp.size(); ++i) accum[i] += tmp[i];
     }
     if (stats) {
@@ -374,7 +381,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         stats->ms_other = timer.ms[2];
         stats->launches_extend = timer.launches[0];
         stats->launches_shade = timer.launches[1];
-        stats->extend_variant = fetch_threshold <= -100 ? 0u : fetch_threshold < 0 ? 1u : 2u;
+        stats->extend_variant = extend_code <= -100 ? 0u : 1u;
         stats->shade_variant = (uint32_t)shade_variant;
         stats->blocks_extend = (uint32_t)grid_extend;
         stats->blocks_shade = (uint32_t)grid_shade;
@@ -409,7 +416,7 @@ extern "C" int pt_intersect(pt_scene* s, const double* rays, uint32_t n, double*
               hip_ok(hipMalloc((void**)&d_o, (size_t)n * 15 * sizeof(double) + 8), "hipMalloc") &&
               hip_ok(hipMemcpyAsync(d_r, rays, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpy");
     if (ok) {
-        launch_probe(s->dev.view, d_r, n, d_o, getenv("PT_PROBE_VARIANT") ? atoi(getenv("PT_PROBE_VARIANT")) : 1 /* fma slab test, like k_extend */, ctx->stream);
+        launch_probe(s->dev.view, d_r, n, d_o, ctx->stream);
         ok = hip_ok(hipMemcpyAsync(out, d_o, (size_t)n * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy") &&
              hip_ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     }

@@ -27,6 +27,10 @@ bool hip_ok(hipError_t e, const char* what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
     return false;
 }
+const char* exp_env(const char* name) {
+    const char* on = getenv("PT_EXPERIMENT");
+    return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
 void DeviceBuffers::release() {
     for (void* p : allocs) (void)hipFree(p);
     allocs.clear();
@@ -543,7 +547,7 @@ int pt::scene_build(pt_scene* s) {
             const uint32_t tri_base = (uint32_t)tris.size();
             if ((size_t)tri_base + o->tris.size() > 0x07FFFFFFu) return set_error("pt_world_build: too many triangles");
             int leaf_max = 4;   // PT_LEAF_MAX: experiments only (smaller leaves were slower on scene 6)
-            if (const char* e = getenv("PT_LEAF_MAX")) leaf_max = std::min(8, std::max(1, atoi(e)));
+            if (const char* e = exp_env("PT_LEAF_MAX")) leaf_max = std::min(8, std::max(1, atoi(e)));
             Builder bl{nodes, items, leaf_max, MAX_BLAS_DEPTH, true, &perm, tri_base};
             Box bb;
             e.blas_root = bl.build(0, items.size(), 0, bb);
@@ -589,7 +593,7 @@ int pt::scene_build(pt_scene* s) {
     uint32_t tlas_root = tl.build(0, tlas_items.size(), 0, wb);
     if (tl.depth_reached + 1 + max_blas_depth + 1 > TRAVERSAL_STACK) return set_error("pt_world_build: BVH too deep for the traversal stack");
     s->stack_need = (uint32_t)(tl.depth_reached + 1 + max_blas_depth + 1);
-    if (getenv("PT_VERBOSE")) fprintf(stderr, "[pt] BVH: top-level depth %d, deepest mesh tree %d, %zu nodes, %zu triangles\n", tl.depth_reached, max_blas_depth, nodes.size(), tris.size());
+    if (exp_env("PT_VERBOSE")) fprintf(stderr, "[pt] BVH: top-level depth %d, deepest mesh tree %d, %zu nodes, %zu triangles\n", tl.depth_reached, max_blas_depth, nodes.size(), tris.size());
 
     // texture atlas
     std::vector<TexD> tex(s->tex.size());
@@ -619,7 +623,7 @@ int pt::scene_build(pt_scene* s) {
     v.n_entries = (uint32_t)entries.size();
     v.n_prims = (uint32_t)prims.size();
     v.n_lights = (uint32_t)lights.size();
-    v.tlas_flat = entries.size() <= TLAS_FLAT_MAX && !getenv("PT_NO_FLAT_TLAS") ? 1u : 0u;
+    v.tlas_flat = entries.size() <= TLAS_FLAT_MAX && !exp_env("PT_NO_FLAT_TLAS") ? 1u : 0u;
     s->stack_need_extend2 = v.tlas_flat ? (uint32_t)(max_blas_depth + 1) : s->stack_need;
     dev.view = v;
     s->n_prims = v.n_prims;

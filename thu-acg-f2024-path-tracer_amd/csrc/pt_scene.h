@@ -22,6 +22,9 @@ namespace pt {
 int set_error(const std::string& msg);   // returns -1
 const char* last_error();
 bool hip_ok(hipError_t e, const char* what);
+// Experiment switches (PT_POOL_SLOTS, PT_SHADE_VARIANT, ...) are read only when PT_EXPERIMENT=1 is set: a release
+// library's behaviour does not depend on stray environment variables, and an explicit option always wins over them.
+const char* exp_env(const char* name);
 
 enum ObjKind { OBJ_SPHERE, OBJ_QUAD, OBJ_CUBOID, OBJ_MESH, OBJ_INSTANCE };
 

@@ -55,3 +55,22 @@ for k in range(0, 2001):
     worst_c = max(worst_c, abs(c - mp.cos(x)) / mp.cos(x))
 print("// relative approximation error with the coefficients rounded to f64: sin", mp.nstr(worst_s, 3), "= 2^", mp.nstr(mp.log(worst_s, 2), 4),
       " cos", mp.nstr(worst_c, 3), "= 2^", mp.nstr(mp.log(worst_c, 2), 4))
+
+
+# ---- exp2 kernel of pow(2^k, y): e^r = 1 + r + r^2/2 + r^3 E(r), |r| <= ln2/2 (+ slack) ----------------------------
+def ge(r):
+    if r == 0:
+        return mp.mpf(1) / 6
+    return (mp.exp(r) - 1 - r - r * r / 2) / r ** 3
+
+
+RMAX = mp.log(2) / 2 + mp.mpf("1e-6")
+for deg in (10, 11, 12):
+    coeffs, err = mp.chebyfit(ge, [-RMAX, RMAX], deg + 1, error=True)
+    print(f"// E degree {deg}: max |fit - g| = {mp.nstr(err, 3)} (relative to e^r: x r^3 <= {mp.nstr(err * RMAX ** 3 / mp.exp(-RMAX), 3)})")
+coeffs = mp.chebyfit(ge, [-RMAX, RMAX], 12)[::-1]
+for i, c in enumerate(coeffs):
+    print(f"    E{i} = {float(c)!r},   // {float(c).hex()}")
+ln2 = mp.log(2)
+hi = float(ln2)
+print(f"// ln2: hi = {hi!r} ({hi.hex()}), lo = {float(ln2 - mp.mpf(hi))!r} ({float(ln2 - mp.mpf(hi)).hex()})")
