@@ -204,7 +204,7 @@ def main():
         }
         out["frame_check"] = frame_check(pt, ctx, args, acc, height)
         if world == 1 and not args.no_cpu_baseline:
-            images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt._SCENE_IMAGES.get(args.scene, [])}
+            images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt.SCENE_IMAGE_FILES.get(args.scene, [])}
             out["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.cpu_seconds, images)
             out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(out), flush=True)

@@ -101,9 +101,14 @@ uint32_t pt_world_prim_count(pt_scene*);
 /* ---- asset ingest (host): the roles of tobj::load_obj (main.rs:408) and
  * ImageReader::open().decode().to_rgb8() (texture.rs:62-67) for .obj / Radiance .hdr ------- */
 int pt_load_obj(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** uv, uint32_t* n_uv);
+/* OBJ with vn and separate v/vt/vn index streams, expanded to ONE index per corner (tobj's single_index): the fix of
+ * mesh.rs:173-184's position-indexed normals / texcoords. Feed the result to pt_mesh. */
+int pt_load_obj_single_index(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** nrm, uint32_t* n_nrm,
+                             float** uv, uint32_t* n_uv);
 int pt_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);
+int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);   /* PNG -> RGB8 (alpha dropped like to_rgb8, texture.rs:67) */
 void pt_free(void*);
-/* images this library does not decode (JPEG/PNG): hand them over decoded, under the file name
+/* images this library does not decode (JPEG): hand them over decoded, under the file name
  * the reference's scene opens ("envmap.jpg", "earthmap.jpg", "bricks/color.png", ...) */
 int pt_register_image(pt_scene*, const char* name, uint32_t w, uint32_t h, const uint8_t* rgb);
 int pt_find_registered_image(pt_scene*, const char* name);   /* texture handle or -1 */

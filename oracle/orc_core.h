@@ -1008,9 +1008,13 @@ struct TriangleMesh : Hittable {  // mesh.rs:144-220
 };
 
 struct Instance : Hittable {  // instance.rs — rotate then translate
-    HitPtr object;
+    HitPtr object;   // Arc<dyn Hittable>: may be shared by several instances and may itself be an Instance (instance.rs:20-30)
     AABB bbox;
     Rigid m;
+    // Canonical primitive ids (the build's tie rule, not the reference's): the wrapped object numbers its primitives
+    // locally from 0 and every instance adds the offset of ITS placement, so an object shared by several instances gets
+    // distinct ids per placement while comparisons inside the object see one consistent order.
+    uint32_t id_offset = 0;
     Instance(HitPtr obj, V3 axis, double angle, V3 translation) : object(obj) {
         m = rigid_from_rotation_translation(quat_from_axis_angle(axis, angle), translation);
         bbox = obj->bounding_box().transformed(m);
@@ -1021,6 +1025,7 @@ struct Instance : Hittable {  // instance.rs — rotate then translate
     bool intersects(const Ray& ray, Interval ray_t, HitInfo& out, Counters& c) const override {  // :34-54
         Ray local = to_local_ray(ray.o, ray.d, ray.time);
         if (!object->intersects(local, ray_t, out, c)) return false;
+        out.prim_id += id_offset;
         out.point = xform_point(m.c0, m.c1, m.c2, m.t, out.point);
         out.geometric_normal = normalize(xform_vector(m.c0, m.c1, m.c2, out.geometric_normal));
         // Q1: shading_normal, front_face, u, v stay as computed in LOCAL space.
@@ -1037,7 +1042,10 @@ struct Instance : Hittable {  // instance.rs — rotate then translate
     double pdf(V3 origin, V3 direction, double time, Counters& c) const override {  // :71-75
         return object->pdf(xform_point(m.i0, m.i1, m.i2, m.it, origin), xform_vector(m.i0, m.i1, m.i2, direction), time, c);
     }
-    uint32_t assign_ids(uint32_t first) override { return object->assign_ids(first); }
+    uint32_t assign_ids(uint32_t first) override {
+        id_offset = first;
+        return first + object->assign_ids(0);
+    }
     uint32_t prim_count() const override { return object->prim_count(); }
 };
 

@@ -229,3 +229,32 @@ def mis_zscores(render, expected, n_batches=16, spp_per_batch=256, seed=3):
     g = batches.mean(axis=(1, 2))                                      # (n_batches, 3) image means
     zg = (g.mean(axis=0) - expected.mean(axis=(0, 1))) / (g.std(axis=0, ddof=1) / np.sqrt(n_batches))
     return z, zg, mean
+
+
+def shared_and_nested_instances_scene(shared=True):
+    """One mesh placed three times through instances (shared geometry when `shared`, three equal mesh objects otherwise),
+    an instance of an instance of that mesh, a twice-wrapped cuboid and a twice-wrapped quad LIGHT (instance.rs:20-75:
+    Instance::new takes any Arc<dyn Hittable>)."""
+    spec = SceneSpec()
+    rgb = lambda r, g, b: spec.add("tex_solid_rgb", r, g, b)
+    floor = spec.add("mat_diffuse", spec.add("tex_checker", 0.8, rgb(0.2, 0.3, 0.1), rgb(0.9, 0.9, 0.9)), -1)
+    metal = spec.add("mat_metal", rgb(0.9, 0.8, 0.6), spec.add("tex_solid_f", 0.15))
+    glass = spec.add("mat_glass", rgb(1.0, 1.0, 1.0), spec.add("tex_solid_f", 0.05), 0.0, 1.5)
+    spec.add("world_add_object", spec.add("quad", (-8.0, 0.0, -8.0), (0.0, 0.0, 16.0), (16.0, 0.0, 0.0), floor))
+    P, I = icosphere(1)
+    mesh = spec.add("mesh", 0.6, P, I, None, None, metal)
+    placements = [((0.0, 1.0, 0.0), 0.3, (-2.0, 0.7, 0.0)), ((1.0, 0.0, 0.0), 1.1, (0.0, 0.7, 0.5)), ((0.0, 0.0, 1.0), -0.7, (2.0, 0.7, -0.5))]
+    for axis, angle, tr in placements:
+        m = mesh if shared else spec.add("mesh", 0.6, P, I, None, None, metal)
+        spec.add("world_add_object", spec.add("instance", m, axis, angle, tr))
+    m = mesh if shared else spec.add("mesh", 0.6, P, I, None, None, metal)
+    inner = spec.add("instance", m, (0.0, 1.0, 0.0), 0.5, (0.3, 0.0, 0.0))
+    spec.add("world_add_object", spec.add("instance", inner, (1.0, 0.0, 0.0), -0.4, (0.0, 2.2, 1.0)))
+    box = spec.add("instance", spec.add("cuboid", (0.0, 0.0, 0.0), (0.7, 0.9, 0.7), glass), (0.0, 1.0, 0.0), 0.6, (0.0, 0.0, 0.0))
+    spec.add("world_add_object", spec.add("instance", box, (0.0, 1.0, 0.0), 0.3, (-1.0, 0.0, 2.2)))
+    lm = spec.add("mat_light", rgb(9.0, 8.0, 7.0))
+    lq = spec.add("instance", spec.add("quad", (-0.6, 0.0, -0.6), (1.2, 0.0, 0.0), (0.0, 0.0, 1.2), lm), (1.0, 0.0, 0.0), 0.2, (0.0, 4.0, 0.0))
+    spec.add("world_add_light", spec.add("instance", lq, (0.0, 0.0, 1.0), -0.15, (0.5, 0.0, 0.5)))
+    spec.add("world_build")
+    spec.camera = default_camera(width=64, look_from=(0.0, 2.0, -6.5), look_at=(0.0, 0.9, 0.0), vfov=45.0, env_color=(0.05, 0.06, 0.09))
+    return spec

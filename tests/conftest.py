@@ -52,7 +52,7 @@ def scene_images(pt):
 
     def get(scene_id):
         if scene_id not in cache:
-            cache[scene_id] = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt._SCENE_IMAGES.get(scene_id, [])}
+            cache[scene_id] = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt.SCENE_IMAGE_FILES.get(scene_id, [])}
         return cache[scene_id]
 
     return get

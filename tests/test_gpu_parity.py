@@ -625,3 +625,40 @@ def test_scene5_3840x2160_properties(pt, det, ctx, scene_images):
         rad, _, _ = os_.trace_sample(ocam, 1, int(pix), 1)
         np.testing.assert_array_equal(flat[pix], rad)
     gs.close(); os_.close()
+
+
+def test_shared_and_nested_instances_bit_exact(pt, det, ctx):
+    """One mesh under three instances (shared tree and triangles, ids per placement), an instance of an instance of it, a
+    twice-wrapped cuboid and a twice-wrapped quad light (lights.sample / lights.pdf through an instance chain): every
+    accumulator value identical to the oracle's Hittable composition (instance.rs:20-75)."""
+    from common import shared_and_nested_instances_scene
+    spec = shared_and_nested_instances_scene(True)
+    gs, os_ = pt.Scene(ctx), det.Scene()
+    gres, ores = spec.replay(gs), spec.replay(os_)
+    assert gs.prim_count() == os_.prim_count() == 1 + 4 * 80 + 6 + 1
+    gcam, ocam = spec.make_camera(pt.Camera, gres), spec.make_camera(det.Camera, ores)
+    ga, st = gs.render(gcam, 5, 0, 8, slots_per_pixel=1)
+    oa, cnt = os_.render(ocam, 5, 0, 8)
+    assert st.segments == cnt["segments"] and st.extend_variant == 0
+    np.testing.assert_array_equal(ga, oa)
+    rng = np.random.default_rng(8)
+    rays = np.zeros((4000, 7))
+    rays[:, 0:3] = rng.uniform(-3, 3, (4000, 3)) + (0.0, 3.0, 0.0)
+    rays[:, 3:6] = rng.normal(size=(4000, 3))
+    g = gs.intersect(rays)
+    np.testing.assert_array_equal(g, os_.intersect(rays))
+    assert len(np.unique(g[g[:, 0] > 0, 2])) > 100                  # hits spread over the placements' id ranges
+    gd, _ = _with_env({"PT_EXPERIMENT": "1", "PT_K2": "batch"}, lambda: gs.render(gcam, 5, 0, 8, slots_per_pixel=1))
+    np.testing.assert_array_equal(gd, oa)                          # the batch form of K2 walks the same chains
+    gs.close(); os_.close()
+    s = pt.Scene(ctx)
+    m = s.mat_diffuse(s.tex_solid_rgb(1, 1, 1))
+    q = s.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
+    i1 = s.instance(q, (0, 1, 0), 0.1, (0, 0, 0))
+    s.instance(q, (0, 1, 0), 0.2, (1, 0, 0))
+    with pytest.raises(pt.PtError, match="already placed"):
+        s.world_add_object(q)
+    s.world_add_object(i1)
+    with pytest.raises(pt.PtError, match="already placed"):
+        s.instance(i1, (0, 1, 0), 0.1, (0, 0, 0))
+    s.close()

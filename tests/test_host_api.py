@@ -111,3 +111,54 @@ def test_cli_and_cpp_mirror_build():
     assert os.path.exists(exe), "run __graft_entry__.build()"
     out = subprocess.run([exe, "--help"], capture_output=True, text=True)
     assert out.returncode == 0 and "-s N" in out.stdout
+
+
+def test_png_decoder_matches_pillow_and_roundtrips(pt, tmp_path):
+    """pt_load_png_rgb8 (zlib inflate + the five scanline filters + colour-type expansion) against Pillow on the
+    reference's own PNG assets (RGBA, 1024^2) and on synthetic files of every colour type / depth Pillow can write."""
+    from PIL import Image
+
+    for n in ("bricks/color.png", "bricks/normal.png"):
+        path = os.path.join(pt.ASSET_DIR, n)
+        np.testing.assert_array_equal(pt.load_png_rgb8(path), np.asarray(Image.open(path).convert("RGB")))
+    rng = np.random.default_rng(0)
+    cases = {"rgb": Image.fromarray(rng.integers(0, 256, (37, 53, 3), dtype=np.uint8), "RGB"),
+             "rgba": Image.fromarray(rng.integers(0, 256, (20, 31, 4), dtype=np.uint8), "RGBA"),
+             "grey": Image.fromarray(rng.integers(0, 256, (19, 23), dtype=np.uint8), "L"),
+             "greya": Image.fromarray(rng.integers(0, 256, (9, 14, 2), dtype=np.uint8), "LA"),
+             "pal": Image.fromarray(rng.integers(0, 256, (33, 17, 3), dtype=np.uint8), "RGB").quantize(16),
+             "bit1": Image.fromarray((rng.integers(0, 2, (13, 29)) * 255).astype(np.uint8), "L").convert("1"),
+             "grey16": Image.fromarray(rng.integers(0, 65536, (11, 7)).astype(np.uint16))}
+    for name, img in cases.items():
+        path = str(tmp_path / f"{name}.png")
+        img.save(path)
+        want = np.asarray(Image.open(path).convert("RGB")) if name != "grey16" else np.repeat((np.asarray(img) >> 8).astype(np.uint8)[..., None], 3, axis=2)
+        np.testing.assert_array_equal(pt.load_png_rgb8(path), want, err_msg=name)
+    png = str(tmp_path / "w.png")                              # the library's own writer (camera.rs:118) read back by its reader
+    px = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    pt.save_png(png, px)
+    np.testing.assert_array_equal(pt.load_png_rgb8(png), px)
+    with pytest.raises(pt.PtError, match="not a PNG"):
+        pt.load_png_rgb8(os.path.join(pt.ASSET_DIR, "earthmap.jpg"))
+
+
+def test_obj_single_index_expansion(pt, tmp_path):
+    """OBJ with vn and separate v/vt/vn streams: every distinct corner becomes one vertex, so the
+    position-indexed attribute lookup of pt_mesh / mesh.rs:173-184 is right. Quads are fan-triangulated, negative indices
+    are relative. On the reference's own meshes (no vn; spot.obj has vt with its own index stream) the positions reached
+    through the new indices equal those of the plain loader."""
+    obj = tmp_path / "t.obj"
+    obj.write_text("\n".join(["v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "vt 0 0", "vt 1 0", "vt 1 1", "vt 0 1", "vn 0 0 1", "vn 0 0 -1",
+                              "f 1/1/1 2/2/1 3/3/1 4/4/1", "f 1/3/2 -2/2/2 2/1/2", ""]))
+    P, I, N, T = pt.load_obj_single_index(str(obj))
+    assert I.tolist() == [0, 1, 2, 0, 2, 3, 4, 5, 6] and len(P) == 7
+    np.testing.assert_array_equal(P[I].reshape(-1, 3), np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 0], [1, 1, 0], [1, 0, 0]], np.float32))
+    np.testing.assert_array_equal(N[[0, 4]], np.array([[0, 0, 1], [0, 0, -1]], np.float32))
+    np.testing.assert_array_equal(T[[4, 5, 6]], np.array([[1, 1], [1, 0], [0, 0]], np.float32))
+    for name in ("bunny.obj", "spot.obj"):
+        path = os.path.join(pt.ASSET_DIR, name)
+        P0, I0, T0 = pt.load_obj(path)
+        P1, I1, N1, T1 = pt.load_obj_single_index(path)
+        assert N1 is None and len(I1) == len(I0)
+        np.testing.assert_array_equal(P1[I1], P0[I0])
+        assert (T1 is None) == (len(T0) == 0)

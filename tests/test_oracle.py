@@ -632,3 +632,32 @@ def test_sphere_light_estimator_bias_is_the_references(orc):
 
 
 BIAS_SPHERE_LIGHT = 16.905   # E[reference estimator] / true integral - 1 for tests/common.py's MIS_SPHERE set-up (quadrature, refs_numpy.py)
+
+
+def test_shared_and_nested_instances(orc):
+    """Instance::new takes an Arc<dyn Hittable> (instance.rs:20-30): one mesh may sit under several instances and an
+    instance may wrap an instance. Sharing must change nothing against three equal mesh objects (ids are per placement),
+    and an object cannot be both placed directly and wrapped."""
+    from common import shared_and_nested_instances_scene
+    accs = []
+    for shared in (True, False):
+        spec = shared_and_nested_instances_scene(shared)
+        s = orc.Scene()
+        cam = spec.make_camera(orc.Camera, spec.replay(s))
+        assert s.prim_count() == 1 + 4 * 80 + 6 + 1
+        acc, cnt = s.render(cam, 5, 0, 4)
+        accs.append((acc, cnt["segments"]))
+        s.close()
+    np.testing.assert_array_equal(accs[0][0], accs[1][0])
+    assert accs[0][1] == accs[1][1] and np.isfinite(accs[0][0]).mean() > 0.99 and accs[0][0].max() > 0
+    s = orc.Scene()
+    m = s.mat_diffuse(s.tex_solid_rgb(1, 1, 1))
+    q = s.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
+    i1 = s.instance(q, (0, 1, 0), 0.1, (0, 0, 0))
+    s.instance(q, (0, 1, 0), 0.2, (1, 0, 0))                       # shared: fine
+    with pytest.raises(Exception, match="already placed"):
+        s.world_add_object(q)                                       # wrapped objects are not placed directly
+    s.world_add_object(i1)
+    with pytest.raises(Exception, match="already placed"):
+        s.instance(i1, (0, 1, 0), 0.1, (0, 0, 0))                   # and placed objects are not wrapped
+    s.close()

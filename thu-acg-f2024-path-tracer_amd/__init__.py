@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "pt_mat_diffuse", "pt_mat_metal", "pt_mat_glass", "pt_mat_principled", "pt_mat_light", "pt_mat_mix", "pt_mat_sheen", "pt_mat_clearcoat",
     "pt_sphere", "pt_quad", "pt_cuboid", "pt_mesh", "pt_instance",
     "pt_world_add_object", "pt_world_add_light", "pt_world_build", "pt_world_prim_count",
-    "pt_load_obj", "pt_load_hdr_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
+    "pt_load_obj", "pt_load_obj_single_index", "pt_load_hdr_rgb8", "pt_load_png_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
     "pt_build_scene", "pt_camera_init", "pt_render", "pt_resolve_u8", "pt_intersect", "pt_math_probe",
     "pt_shard_range", "pt_comm_create", "pt_comm_destroy", "pt_comm_rank", "pt_comm_world", "pt_comm_barrier", "pt_comm_allreduce_f64",
     "pt_bootstrap_exchange", "pt_render_multi",
@@ -152,8 +152,14 @@ def _load():
     lib.pt_load_obj.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32)),
                                 C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32)]
     lib.pt_load_hdr_rgb8.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if hasattr(lib, "pt_load_png_rgb8"):
+        lib.pt_load_png_rgb8.argtypes = lib.pt_load_hdr_rgb8.argtypes
+        fp, up = C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32)
+        lib.pt_load_obj_single_index.argtypes = [C.c_char_p, fp, up, C.POINTER(C.POINTER(C.c_uint32)), up, fp, up, fp, up]
     lib.pt_free.argtypes = [C.c_void_p]
     lib.pt_free.restype = None
+    if os.environ.get("PT_AMD_LIB") and not hasattr(lib, "pt_shard_range"):
+        return lib                                   # A/B run against a build that predates the multi-GPU entry points
     lib.pt_shard_range.argtypes = [C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pt_shard_range.restype = None
     lib.pt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_double, C.POINTER(C.c_void_p)]
@@ -374,7 +380,9 @@ class Scene:
 
 
 # images each scene script opens that the C++ host cannot decode itself (JPEG / PNG)
-_SCENE_IMAGES = {2: ["earthmap.jpg"], 5: ["envmap.jpg"], 7: ["bricks/color.png", "bricks/normal.png"]}
+_SCENE_IMAGES = {2: ["earthmap.jpg"], 5: ["envmap.jpg"]}     # JPEG only: PNG (scene 7) and Radiance HDR are decoded by the library
+# every non-HDR image a scene script opens (for hosts that decode everything themselves, e.g. the test oracle via Pillow)
+SCENE_IMAGE_FILES = {2: ["earthmap.jpg"], 5: ["envmap.jpg"], 7: ["bricks/color.png", "bricks/normal.png"]}
 
 
 def camera_init(cam: Camera):
@@ -400,6 +408,29 @@ def load_obj(path: str):
     T = np.ctypeslib.as_array(uv, (nuv.value * 2,)).copy().reshape(-1, 2) if nuv.value else np.zeros((0, 2), np.float32)
     lib.pt_free(pos); lib.pt_free(idx); lib.pt_free(uv)
     return P, I, T
+
+
+def load_obj_single_index(path: str):
+    """OBJ with vn / separate index streams -> (positions, indices, normals | None, texcoords | None), one index per corner."""
+    pos, idx, nrm, uv = C.POINTER(C.c_float)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+    npos, nidx, nnrm, nuv = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _check(lib.pt_load_obj_single_index(path.encode(), C.byref(pos), C.byref(npos), C.byref(idx), C.byref(nidx), C.byref(nrm), C.byref(nnrm),
+                                        C.byref(uv), C.byref(nuv)), "pt_load_obj_single_index")
+    arr = lambda p, n, k, dt: np.ctypeslib.as_array(p, (n * k,)).copy().reshape(-1, k) if n else None
+    out = (arr(pos, npos.value, 3, np.float32), np.ctypeslib.as_array(idx, (nidx.value,)).copy() if nidx.value else np.zeros(0, np.uint32),
+           arr(nrm, nnrm.value, 3, np.float32), arr(uv, nuv.value, 2, np.float32))
+    for p in (pos, idx, nrm, uv):
+        lib.pt_free(p)
+    return out
+
+
+def load_png_rgb8(path: str) -> np.ndarray:
+    p = C.POINTER(C.c_uint8)()
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib.pt_load_png_rgb8(path.encode(), C.byref(p), C.byref(w), C.byref(h)), "pt_load_png_rgb8")
+    img = np.ctypeslib.as_array(p, (h.value, w.value, 3)).copy()
+    lib.pt_free(p)
+    return img
 
 
 def load_hdr_rgb8(path: str) -> np.ndarray:

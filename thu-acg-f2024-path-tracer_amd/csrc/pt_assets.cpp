@@ -3,6 +3,7 @@
 // and PNG output (imgbuf.save, camera.rs:118). None of this is on the hot path.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +67,156 @@ extern "C" int pt_load_obj(const char* path, float** pos, uint32_t* n_pos, uint3
     *pos = to_malloc(P); *n_pos = (uint32_t)(P.size() / 3);
     *idx = to_malloc(I); *n_idx = (uint32_t)I.size();
     *uv = to_malloc(T); *n_uv = (uint32_t)(T.size() / 2);
+    return 0;
+}
+
+// OBJ with `vn` and separate v/vt/vn index streams: single-index expansion (what tobj does with `single_index: true`).
+// The reference indexes normals and texcoords with the POSITION index (mesh.rs:173-184, under tobj's
+// OFFLINE_RENDERING_LOAD_OPTIONS) — right only for files whose three index streams coincide. Here every distinct
+// (v, vt, vn) corner becomes one output vertex, in order of first appearance, so that pt_mesh's position-indexed
+// attribute lookup is right for any file. n_nrm / n_uv are 0 when the file has no vn / vt, or when a face omits them.
+#include <map>
+#include <tuple>
+extern "C" int pt_load_obj_single_index(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** nrm,
+                                        uint32_t* n_nrm, float** uv, uint32_t* n_uv) {
+    std::ifstream in(path);
+    if (!in) return set_error(std::string("pt_load_obj_single_index: cannot open ") + path);
+    std::vector<float> P, T, N, oP, oT, oN;
+    std::vector<uint32_t> I;
+    std::map<std::tuple<long, long, long>, uint32_t> seen;
+    bool all_uv = true, all_nrm = true;
+    std::string line, tag, corner;
+    auto f3 = [&](std::istringstream& ls, std::vector<float>& dst, int n) {
+        for (int k = 0; k < n; ++k) {
+            std::string a;
+            if (!(ls >> a)) return false;
+            dst.push_back(strtof(a.c_str(), nullptr));
+        }
+        return true;
+    };
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        if (!(ls >> tag)) continue;
+        if (tag == "v") { if (!f3(ls, P, 3)) return set_error("pt_load_obj_single_index: malformed vertex"); }
+        else if (tag == "vt") { if (!f3(ls, T, 2)) return set_error("pt_load_obj_single_index: malformed texcoord"); }
+        else if (tag == "vn") { if (!f3(ls, N, 3)) return set_error("pt_load_obj_single_index: malformed normal"); }
+        else if (tag == "f") {
+            std::vector<uint32_t> poly;
+            const long nv = (long)(P.size() / 3), nt = (long)(T.size() / 2), nn = (long)(N.size() / 3);
+            while (ls >> corner) {
+                long c[3] = {0, 0, 0};   // 1-based v, vt, vn; 0 = absent
+                const char* q = corner.c_str();
+                for (int k = 0; k < 3 && *q; ++k) {
+                    char* end;
+                    c[k] = strtol(q, &end, 10);
+                    q = end;
+                    if (*q == '/') ++q;
+                }
+                auto fix = [](long i, long n) { return i < 0 ? n + i : i - 1; };   // negative = relative to the end
+                const long v = fix(c[0], nv), t = c[1] ? fix(c[1], nt) : -1, n = c[2] ? fix(c[2], nn) : -1;
+                if (v < 0 || v >= nv || t >= nt || n >= nn || (c[1] && t < 0) || (c[2] && n < 0)) return set_error("pt_load_obj_single_index: face index out of range");
+                all_uv = all_uv && t >= 0;
+                all_nrm = all_nrm && n >= 0;
+                auto key = std::make_tuple(v, t, n);
+                auto it = seen.find(key);
+                if (it == seen.end()) {
+                    it = seen.emplace(key, (uint32_t)(oP.size() / 3)).first;
+                    for (int k = 0; k < 3; ++k) oP.push_back(P[3 * v + k]);
+                    for (int k = 0; k < 2; ++k) oT.push_back(t >= 0 ? T[2 * t + k] : 0.0f);
+                    for (int k = 0; k < 3; ++k) oN.push_back(n >= 0 ? N[3 * n + k] : 0.0f);
+                }
+                poly.push_back(it->second);
+            }
+            for (size_t k = 1; k + 1 < poly.size(); ++k) { I.push_back(poly[0]); I.push_back(poly[k]); I.push_back(poly[k + 1]); }
+        }
+    }
+    if (!all_uv || T.empty()) oT.clear();
+    if (!all_nrm || N.empty()) oN.clear();
+    *pos = to_malloc(oP); *n_pos = (uint32_t)(oP.size() / 3);
+    *idx = to_malloc(I); *n_idx = (uint32_t)I.size();
+    *nrm = to_malloc(oN); *n_nrm = (uint32_t)(oN.size() / 3);
+    *uv = to_malloc(oT); *n_uv = (uint32_t)(oT.size() / 2);
+    return 0;
+}
+
+// PNG -> RGB8 (role of image's PngDecoder + to_rgb8(), texture.rs:62-67: alpha dropped, grey replicated, 16-bit samples
+// keep their high byte, palettes expanded). zlib inflates the IDAT stream; the five scanline filters are undone here.
+// Interlaced (Adam7) files are rejected.
+extern "C" int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return set_error(std::string("pt_load_png_rgb8: cannot open ") + path);
+    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (f.size() < 8 || memcmp(f.data(), sig, 8) != 0) return set_error("pt_load_png_rgb8: not a PNG file");
+    auto be32 = [&](size_t p) { return ((uint32_t)f[p] << 24) | ((uint32_t)f[p + 1] << 16) | ((uint32_t)f[p + 2] << 8) | f[p + 3]; };
+    uint32_t W = 0, H = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    for (size_t p = 8; p + 12 <= f.size();) {
+        const uint32_t len = be32(p);
+        if (p + 12 + (size_t)len > f.size()) return set_error("pt_load_png_rgb8: truncated chunk");
+        const std::string type((const char*)&f[p + 4], 4);
+        const uint8_t* d = &f[p + 8];
+        if (crc32(crc32(0, nullptr, 0), &f[p + 4], len + 4) != be32(p + 8 + len)) return set_error("pt_load_png_rgb8: chunk CRC mismatch");
+        if (type == "IHDR") {
+            if (len < 13) return set_error("pt_load_png_rgb8: bad IHDR");
+            W = be32(p + 8); H = be32(p + 12);
+            depth = d[8]; ctype = d[9]; interlace = d[12];
+        } else if (type == "PLTE") plte.assign(d, d + len);
+        else if (type == "IDAT") idat.insert(idat.end(), d, d + len);
+        else if (type == "IEND") break;
+        p += 12 + (size_t)len;
+    }
+    if (W == 0 || H == 0 || (uint64_t)W * H > (1ull << 31)) return set_error("pt_load_png_rgb8: bad image size");
+    if (interlace) return set_error("pt_load_png_rgb8: interlaced PNG is not supported");
+    const int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!chans || !(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
+        return set_error("pt_load_png_rgb8: unsupported colour type / bit depth");
+    if (ctype == 3 && plte.size() < 3) return set_error("pt_load_png_rgb8: palette image without PLTE");
+    const size_t bpp = std::max<size_t>(1, (size_t)chans * depth / 8), stride = ((size_t)W * chans * depth + 7) / 8;
+    std::vector<uint8_t> raw((stride + 1) * H);
+    uLongf out_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return set_error("pt_load_png_rgb8: zlib stream is damaged");
+    std::vector<uint8_t> prev(stride, 0), out((size_t)W * H * 3);
+    for (uint32_t y = 0; y < H; ++y) {
+        uint8_t* row = &raw[(size_t)y * (stride + 1)];
+        const int ft = row[0];
+        uint8_t* cur = row + 1;
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) {
+                const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            } else if (ft != 0) return set_error("pt_load_png_rgb8: bad filter type");
+            cur[i] = (uint8_t)(cur[i] + pred);
+        }
+        memcpy(prev.data(), cur, stride);
+        auto sample = [&](uint32_t x, int ch) -> uint8_t {   // 8-bit value of channel ch of pixel x
+            if (depth == 8) return cur[(size_t)x * chans + ch];
+            if (depth == 16) return cur[((size_t)x * chans + ch) * 2];
+            const size_t bit = (size_t)x * depth;
+            const int v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+            return ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+        };
+        for (uint32_t x = 0; x < W; ++x) {
+            uint8_t* o = &out[((size_t)y * W + x) * 3];
+            if (ctype == 3) {
+                const size_t k = sample(x, 0);
+                if (3 * k + 2 >= plte.size()) return set_error("pt_load_png_rgb8: palette index out of range");
+                o[0] = plte[3 * k]; o[1] = plte[3 * k + 1]; o[2] = plte[3 * k + 2];
+            } else if (chans <= 2) {
+                o[0] = o[1] = o[2] = sample(x, 0);
+            } else {
+                o[0] = sample(x, 0); o[1] = sample(x, 1); o[2] = sample(x, 2);
+            }
+        }
+    }
+    *rgb = to_malloc(out);
+    *w = W; *h = H;
     return 0;
 }
 

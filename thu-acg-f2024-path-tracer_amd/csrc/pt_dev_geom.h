@@ -18,6 +18,28 @@ PT_DEV RayD ray_to_local(const InstD& m, const RayD& r) {
     return make_ray(xform_point(m.i0, m.i1, m.i2, m.it, r.o), xform_vector(m.i0, m.i1, m.i2, r.d), r.time);
 }
 
+// Ray into the object space of a placement: Instance::intersects' transform (instance.rs:36-38, Ray::new re-normalises)
+// of every instance of the chain, outermost first. U: the chain is wave-uniform (scalar loads). `innermost` receives the
+// last index visited (the start of the way back: to_world_chain).
+template <bool U = false>
+PT_DEV RayD ray_to_local_chain(const SceneD& sc, int32_t outermost, RayD r, int32_t* innermost = nullptr) {
+    int32_t last = -1;
+    for (int32_t i = outermost; i >= 0;) {
+        last = i;
+        if constexpr (U) {
+            const InstD m = ldu(&sc.insts[i]);
+            r = ray_to_local(m, r);
+            i = m.inner;
+        } else {
+            const InstD& m = sc.insts[i];
+            r = ray_to_local(m, r);
+            i = m.inner;
+        }
+    }
+    if (innermost) *innermost = last;
+    return r;
+}
+
 // sphere.rs:64-87 — open interval (t_min, +inf)
 PT_DEV bool hit_sphere(const SphereD& s, const RayD& r, double t_min, double& t, V3& center) {
     center = ld3(s.p1) + (ld3(s.p2) - ld3(s.p1)) * r.time;
@@ -99,8 +121,8 @@ PT_DEV void finish_hit(const SceneD& sc, const RayD& r, V3 point, V3 normal, dou
 // same t/u/v bits), then applies Instance::intersects' world transform (instance.rs:43-53, Q1).
 PT_DEV bool reconstruct_hit(const SceneD& sc, const RayD& world_ray, uint32_t gid, double t_min, HitD& h) {
     const PrimRef pr = sc.prims[gid];
-    RayD r = world_ray;
-    if (pr.inst >= 0) r = ray_to_local(sc.insts[pr.inst], world_ray);
+    int32_t innermost = -1;
+    const RayD r = ray_to_local_chain(sc, pr.inst, world_ray, &innermost);
     const uint32_t kind = pr.kind & 0xFFu;
     if (kind == PRIM_SPHERE) {
         double t;
@@ -138,10 +160,11 @@ PT_DEV bool reconstruct_hit(const SceneD& sc, const RayD& world_ray, uint32_t gi
         }
         finish_hit(sc, r, ray_at(r, t), normal, t, pr.mat, tu, tv, h);
     }
-    if (pr.inst >= 0) {
-        const InstD& m = sc.insts[pr.inst];
+    for (int32_t i = innermost; i >= 0;) {                                       // instance.rs:43-53, innermost instance first
+        const InstD& m = sc.insts[i];
         h.point = xform_point(m.c0, m.c1, m.c2, m.t, h.point);
         h.gn = normalize(xform_vector(m.c0, m.c1, m.c2, h.gn));
+        i = m.outer;
     }
     return true;
 }
@@ -167,9 +190,12 @@ PT_DEV V3 lights_sample(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
     uint32_t i = rng_index(rng, sc.n_lights);
     const Entry e = sc.entries[sc.lights[i]];
     V3 origin = origin_w;
-    if (e.inst >= 0) {                                                            // instance.rs:64-66
-        const InstD& m = sc.insts[e.inst];
-        origin = xform_point(m.i0, m.i1, m.i2, m.it, origin_w);
+    int32_t innermost = -1;
+    for (int32_t k = e.inst; k >= 0;) {                                           // instance.rs:64-66, outermost instance first
+        const InstD& m = sc.insts[k];
+        origin = xform_point(m.i0, m.i1, m.i2, m.it, origin);
+        innermost = k;
+        k = m.inner;
     }
     V3 dir;
     if (e.kind == ENTRY_QUAD) {
@@ -195,9 +221,10 @@ PT_DEV V3 lights_sample(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
         V3 point = center + V3{sp * ct, sp * st, cp} * s.r;
         dir = normalize(point - origin);
     }
-    if (e.inst >= 0) {                                                            // instance.rs:67-68 (not re-normalised)
-        const InstD& m = sc.insts[e.inst];
+    for (int32_t k = innermost; k >= 0;) {                                        // instance.rs:67-68 (not re-normalised)
+        const InstD& m = sc.insts[k];
         dir = xform_vector(m.c0, m.c1, m.c2, dir);
+        k = m.outer;
     }
     return dir;
 }
@@ -207,10 +234,11 @@ PT_DEV double lights_pdf(const SceneD& sc, V3 origin_w, V3 direction_w, double t
     for (uint32_t i = 0; i < sc.n_lights; ++i) {                                  // the light index is wave-uniform: scalar loads (ldu)
         const Entry e = ldu(&sc.entries[ldu(&sc.lights[i])]);
         V3 origin = origin_w, direction = direction_w;
-        if (e.inst >= 0) {                                                        // instance.rs:71-75
-            const InstD m = ldu(&sc.insts[e.inst]);
-            origin = xform_point(m.i0, m.i1, m.i2, m.it, origin_w);
-            direction = xform_vector(m.i0, m.i1, m.i2, direction_w);
+        for (int32_t k = e.inst; k >= 0;) {                                       // instance.rs:71-75, outermost instance first
+            const InstD m = ldu(&sc.insts[k]);
+            origin = xform_point(m.i0, m.i1, m.i2, m.it, origin);
+            direction = xform_vector(m.i0, m.i1, m.i2, direction);
+            k = m.inner;
         }
         double pdf = 0.0;
         if (e.kind == ENTRY_QUAD) {

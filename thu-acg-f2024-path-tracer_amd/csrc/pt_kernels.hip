@@ -60,6 +60,10 @@ PT_DEV void store_path(const PoolD& pool, uint32_t s, V3 thr, uint32_t pixel) {
     d2v* p = reinterpret_cast<d2v*>(&pool.path[s]);
     p[0] = d2v{thr.x, thr.y};
     *reinterpret_cast<u4v*>(p + 1) = u4v{(uint32_t)__double2loint(thr.z), (uint32_t)__double2hiint(thr.z), pixel, 0u};
+#if PT_PATHREC_BYTES == 64
+    p[2] = d2v{0.0, 0.0};                         // the record is one 64-B sector: write all of it
+    p[3] = d2v{0.0, 0.0};
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -78,6 +82,17 @@ PT_DEV void consider(Closest& best, double t, uint32_t id) {
         best.id = id;
     }
 }
+// K2's result word for a slot (pt_types.h, PoolD::hit_prim): id | class << 28. `id` may be one of the sentinels.
+PT_DEV uint32_t hit_word(const SceneD& sc, uint32_t id) {
+    if (id >= HIT_SLOT_DEAD) {
+        const uint32_t cls = id == HIT_NONE ? CLASS_MISS : id == HIT_SLOT_IDLE ? CLASS_IDLE : CLASS_DEAD;
+        return (cls << HIT_CLASS_SHIFT) | HIT_ID_MASK;
+    }
+    const uint32_t mat_kind = (sc.prims[id].kind >> PRIM_MAT_KIND_SHIFT) & 0xFFu;
+    return ((1u + mat_kind) << HIT_CLASS_SHIFT) | id;
+}
+PT_DEV uint32_t dead_or_idle(uint32_t bounce) { return bounce == SLOT_IDLE ? HIT_SLOT_IDLE : HIT_SLOT_DEAD; }
+
 // ---- conservative f32 slab test -----------------------------------------------------------------
 // Per ray and per space (world / instance-local) the f64 ray is reduced to idf = fl32(1/d),
 // oif = fl32(o/d) and t' = fma32(b, idf, -oif) for a box bound b. Error analysis (u = 2^-24):
@@ -174,6 +189,7 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
     float t_max_f = t_max_f32(best.t);
     int sp = 0;
     uint32_t cur = sc.tlas_root;
+    uint32_t mesh_first_prim = 0;   // Entry::first_prim of the mesh instance being walked
     for (;;) {
         if ((cur & REF_TYPE_MASK) == REF_NODE) {
             const BvhNode* nd = &sc.nodes[cur];
@@ -188,15 +204,15 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
             for (uint32_t i = first; i < first + count; ++i) {
                 double t, u, v;
-                if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
+                if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, mesh_first_prim + sc.tri_gid[i]);
             }
             t_max_f = t_max_f32(best.t);
         } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
             const Entry e = sc.entries[cur & 0x3FFFFFFFu];
-            RayD lr = wray;
-            if (e.inst >= 0) lr = ray_to_local(sc.insts[e.inst], wray);
+            const RayD lr = ray_to_local_chain(sc, e.inst, wray);
             if (e.kind == ENTRY_MESH) {
                 r = lr;
+                mesh_first_prim = e.first_prim;
                 f = make_rayf(r.o, r.d, e.extent);
                 if (sp < TRAVERSAL_STACK) stk[(sp++) * BLOCK] = REF_LEAVE_INSTANCE;
                 cur = e.blas_root;
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
             pool.ax[s] = 0.0; pool.ay[s] = 0.0; pool.az[s] = 0.0;
             pool.rx[s] = 0.0; pool.ry[s] = 0.0; pool.rz[s] = 0.0;
         }
-        pool.hit_prim[s] = HIT_NONE;
+        pool.hit_prim[s] = (CLASS_DEAD << HIT_CLASS_SHIFT) | HIT_ID_MASK;   // overwritten by the first K2 launch
         store_path(pool, s, V3{1.0, 1.0, 1.0}, pixel);
         if (!has_work || idle) {
             pool.bounce[s] = idle ? SLOT_IDLE : SLOT_DEAD;
@@ -281,8 +297,7 @@ PT_DEV Closest closest_hit_flat(const SceneD& sc, bool alive, const RayD& r, dou
             if (e.kind == ENTRY_MESH) {
                 blas_pass(sc, r, e, t_min, t_min_f, stk, TRAVERSAL_STACK, best);
             } else {
-                RayD lr = r;
-                if (e.inst >= 0) lr = ray_to_local(ldu(&sc.insts[e.inst]), r);
+                const RayD lr = ray_to_local_chain<true>(sc, e.inst, r);
                 const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
                 for (uint32_t i = 0; i < n; ++i) test_world_prim<true>(sc, lr, t_min, e.first_prim + i, best);
             }
@@ -303,16 +318,15 @@ __global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, Counter
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
     // n_alloc is a multiple of BLOCK: whole waves run every chunk (closest_hit_flat ballots)
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
-        const bool alive = pool.bounce[s] < SLOT_IDLE;
+        const uint32_t state = pool.bounce[s];
+        const bool alive = state < SLOT_IDLE;
         RayD r{};
         if (alive) r = load_ray(pool, s);
         Closest c{D_INF, HIT_NONE};
         if (FLAT) c = closest_hit_flat(sc, alive, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
         else if (alive) c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);
-        if (alive) {
-            stnt(&pool.hit_prim[s], (uint32_t)(c.id));
-            ++nseg;
-        }
+        stnt(&pool.hit_prim[s], hit_word(sc, alive ? c.id : dead_or_idle(state)));
+        if (alive) ++nseg;
     }
     if (nseg) atomicAdd(&cnt->segments, nseg);
 }
@@ -345,8 +359,7 @@ constexpr uint32_t REFILL_MIN = 16;   // idle lanes that trigger a refill of the
 constexpr int EXT_CAND = 768;      // candidate list of a window (LDS); a fuller window walks the rest in phase A
 
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
-    RayD r = wray;
-    if (e.inst >= 0) r = ray_to_local(sc.insts[e.inst], wray);
+    const RayD r = ray_to_local_chain(sc, e.inst, wray);
     const RayF f = make_rayf(r.o, r.d, e.extent);
     float t_max_f = t_max_f32(best.t);
     int sp = 0;
@@ -367,7 +380,7 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
         const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
         for (uint32_t i = first; i < first + count; ++i) {
             double t, u, v;
-            if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
+            if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, e.first_prim + sc.tri_gid[i]);
         }
         t_max_f = t_max_f32(best.t);
         if (sp == 0) break;
@@ -398,16 +411,17 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         // ---- phase A: top level only ---------------------------------------------------------------
         // the ray of the NEXT chunk is requested before this chunk's traversal starts: with three waves per
         // SIMD nothing else hides the 2-3 us an HBM fetch takes
-        bool alive_next = pool.bounce[wbase + threadIdx.x] < SLOT_IDLE;
+        uint32_t state_next = pool.bounce[wbase + threadIdx.x];
         RayD r_next{};
-        if (alive_next) r_next = load_ray(pool, wbase + threadIdx.x);
+        if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + threadIdx.x);
         for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) {
             const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x;
-            const bool alive = alive_next;
+            const uint32_t state = state_next;
+            const bool alive = state < SLOT_IDLE;
             const RayD r = r_next;
             if (j + 1 < EXT_WINDOW / BLOCK) {
-                alive_next = pool.bounce[wbase + sl + BLOCK] < SLOT_IDLE;
-                if (alive_next) r_next = load_ray(pool, wbase + sl + BLOCK);
+                state_next = pool.bounce[wbase + sl + BLOCK];
+                if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + sl + BLOCK);
             }
             uint32_t n_my = 0, items = 0xFFFFFFFFu;
             RayF f{};
@@ -429,11 +443,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                         t_max_f = t_max_f32(best.t);
                     }
                 } else {
-                    RayD lr = r;
-                    if (e.inst >= 0) {
-                        if constexpr (U) lr = ray_to_local(ldu(&sc.insts[e.inst]), r);
-                        else lr = ray_to_local(sc.insts[e.inst], r);
-                    }
+                    const RayD lr = ray_to_local_chain<U>(sc, e.inst, r);
                     const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;       // cuboid.rs: six quads, linear
                     for (uint32_t i = 0; i < n; ++i) test_world_prim<U>(sc, lr, t_min, e.first_prim + i, best);
                     t_max_f = t_max_f32(best.t);
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                     }
                 }
             }
-            s_best_id[sl] = alive ? best.id : HIT_NONE;
+            s_best_id[sl] = alive ? best.id : dead_or_idle(state);
         }
         __syncthreads();
         // ---- phase B: mesh traversals, 64 rays per pull ------------------------------------------------
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
             // when at least REFILL_MIN lanes of the wave are idle they draw the next candidates from the list (one
             // LDS atomic per wave) and the wave goes on with every lane at its own ray. s_next counts RAYS here.
             bool busy = false, exhausted = false;                   // exhausted: wave-uniform, the list has run out
-            uint32_t sl = 0, items = 0, item_k = 0, cur = REF_EMPTY;
+            uint32_t sl = 0, items = 0, item_k = 0, cur = REF_EMPTY, first_prim = 0;
             int sp = 0;
             RayD wr{}, r{};
             RayF f{};
@@ -510,8 +520,8 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 const uint32_t ei = item_k < 4u ? (items >> (8u * item_k)) & 0xFFu : 0xFFu;
                 if (ei == 0xFFu) return false;
                 const Entry e = sc.entries[ei];
-                r = wr;
-                if (e.inst >= 0) r = ray_to_local(sc.insts[e.inst], wr);
+                r = ray_to_local_chain(sc, e.inst, wr);
+                first_prim = e.first_prim;
                 f = make_rayf(r.o, r.d, e.extent);
                 t_max_f = t_max_f32(best.t);
                 cur = e.blas_root;
@@ -556,7 +566,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                         const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
                         for (uint32_t i = first; i < first + count; ++i) {
                             double t, u, v;
-                            if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, sc.tri_gid[i]);
+                            if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, first_prim + sc.tri_gid[i]);
                         }
                         t_max_f = t_max_f32(best.t);
                         cur = sp > 0 ? stk[(--sp) * BLOCK] : REF_EMPTY;
@@ -572,9 +582,12 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
             }
         }
         __syncthreads();
-        for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) {   // the window's result: one coalesced 4-byte store per slot
-            const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x;
-            stnt(&pool.hit_prim[wbase + sl], s_best_id[sl]);
+        {   // the window's result: one coalesced 4-byte store per slot; the eight PrimRef gathers (material class) go out together
+            uint32_t word[EXT_WINDOW / BLOCK];
+#pragma unroll
+            for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) word[j] = hit_word(sc, s_best_id[(uint32_t)j * BLOCK + threadIdx.x]);
+#pragma unroll
+            for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) stnt(&pool.hit_prim[wbase + (uint32_t)j * BLOCK + threadIdx.x], word[j]);
         }
         __syncthreads();   // LDS lists are reused by the next window
     }
@@ -616,9 +629,10 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         }
         ray = load_ray(pool, s, sample, draw);
         rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, draw};
-        const uint32_t gid = pool.hit_prim[s];
+        const uint32_t hw = pool.hit_prim[s];
+        const uint32_t gid = hw & HIT_ID_MASK;
         HitD hit;
-        if (gid == HIT_NONE || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
+        if ((hw >> HIT_CLASS_SHIFT) == CLASS_MISS || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
             add_radiance(pool, pixel, rad, thr * sample_environment(sc, cam, ray.d));   // camera.rs:180-183
             finished = true;
         } else {
@@ -742,7 +756,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             shade_slot(sc, cam, pool, cnt, seed, base + threadIdx.x, lane, true, shard, n_done, n_died);
     } else {
         __shared__ uint16_t s_perm[SORT_WINDOW];
-        constexpr uint32_t NCLASS = 3u + MAT_KINDS, K_IDLE = 1u + MAT_KINDS, K_DEAD = 2u + MAT_KINDS;   // miss, one per material kind, idle, dead
+        constexpr uint32_t NCLASS = N_CLASSES, K_DEAD = CLASS_DEAD;   // miss, one per material kind, idle, dead
         __shared__ uint32_t s_cnt[NCLASS][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
         __shared__ uint32_t s_hist[NCLASS], s_next;
         constexpr int PER = SORT_WINDOW / BLOCK, NGRP = SORT_WINDOW / 64;
@@ -755,22 +769,14 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             if (s_win >= n_windows) break;
             const uint32_t wbase = s_win * SORT_WINDOW;
             // classify; STABLE counting sort (slot order is kept inside a class, so the work items a
-            // wave dequeues — consecutive pixels of one tile — stay together in a group). The material
-            // kind travels in PrimRef::kind (bits 16..23): one dependent load after hit_prim, not two.
-            uint32_t keys = 0;   // 8 x 4-bit class keys
+            // wave dequeues — consecutive pixels of one tile — stay together in a group).
+            uint32_t keys = 0;   // 8 x 4-bit class keys: K2 left the class in the top bits of its result word
             uint32_t rank[PER];
 #pragma unroll
+            for (int j = 0; j < PER; ++j) keys |= (pool.hit_prim[wbase + (uint32_t)j * BLOCK + threadIdx.x] >> HIT_CLASS_SHIFT) << (4 * j);
+#pragma unroll
             for (int j = 0; j < PER; ++j) {
-                const uint32_t s0 = wbase + (uint32_t)j * BLOCK + threadIdx.x;
-                const uint32_t b0 = pool.bounce[s0];
-                uint32_t key;
-                if (b0 == SLOT_DEAD) key = K_DEAD;
-                else if (b0 == SLOT_IDLE) key = K_IDLE;
-                else {
-                    const uint32_t g0 = pool.hit_prim[s0];
-                    key = g0 == HIT_NONE ? 0u : 1u + ((sc.prims[g0].kind >> PRIM_MAT_KIND_SHIFT) & 0xFFu);
-                }
-                keys |= key << (4 * j);
+                const uint32_t key = (keys >> (4 * j)) & 15u;
                 rank[j] = 0;
                 for (uint32_t k = 0; k < NCLASS; ++k)
                     if (lane == 0) s_cnt[k][j * (BLOCK / 64) + wave] = 0;

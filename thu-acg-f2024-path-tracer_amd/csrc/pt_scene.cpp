@@ -256,9 +256,8 @@ extern "C" int pt_mesh(pt_scene* s, double scale, uint32_t n_pos, const float* p
 }
 extern "C" int pt_instance(pt_scene* s, int obj, const double axis[3], double angle, const double tr[3]) {   // instance.rs:20-30
     if (!OBJ_OK(s, obj)) return set_error("pt_instance: bad object handle");
-    if (s->objs[obj].kind == OBJ_INSTANCE) return set_error("pt_instance: nested instances are not supported");
-    if (s->objs[obj].used) return set_error("pt_instance: object is already placed (each object may be used once)");
-    s->objs[obj].used = true;
+    if (s->objs[obj].placed) return set_error("pt_instance: object is already placed in the world");
+    s->objs[obj].wrapped = true;   // may be wrapped again (shared geometry), and may itself be an instance (nesting)
     HostObj o;
     o.kind = OBJ_INSTANCE;
     o.child = obj;
@@ -283,12 +282,13 @@ extern "C" int pt_instance(pt_scene* s, int obj, const double axis[3], double an
     D3 it = -xform_vector(i0, i1, i2, t);
     st3(o.xf.c0, c0); st3(o.xf.c1, c1); st3(o.xf.c2, c2); st3(o.xf.t, t);
     st3(o.xf.i0, i0); st3(o.xf.i1, i1); st3(o.xf.i2, i2); st3(o.xf.it, it);
+    o.xf.inner = o.xf.outer = -1;
     return push_obj(s, std::move(o));
 }
 static int place(pt_scene* s, int obj, std::vector<int>& list, const char* who) {
     if (!OBJ_OK(s, obj)) return set_error(std::string(who) + ": bad object handle");
-    if (s->objs[obj].used) return set_error(std::string(who) + ": object is already placed (each object may be used once)");
-    s->objs[obj].used = true;
+    if (s->objs[obj].placed || s->objs[obj].wrapped) return set_error(std::string(who) + ": object is already placed (directly, or through an instance)");
+    s->objs[obj].placed = true;
     list.push_back(obj);
     s->built = false;
     return 0;
@@ -500,15 +500,37 @@ int pt::scene_build(pt_scene* s) {
     order.insert(order.end(), s->world_objects.begin(), s->world_objects.end());
     if (order.empty()) return set_error("pt_world_build: the world is empty");
     int max_blas_depth = 0;
+    struct SharedBlas {   // one tree and one triangle range per MESH OBJECT, however many placements it has
+        uint32_t root, tri_base;
+        float extent;
+        Box local;
+        std::vector<uint32_t> face_pos;   // face -> position in BLAS (leaf) order
+    };
+    std::map<int, SharedBlas> blas_of;
     for (size_t wi = 0; wi < order.size(); ++wi) {
-        const HostObj* top = &s->objs[order[wi]];
+        // the placement's instance chain, outermost first, down to the object it finally wraps
+        int oi = order[wi];
         int inst = -1;
-        const HostObj* o = top;
-        if (top->kind == OBJ_INSTANCE) {
-            inst = (int)insts.size();
-            insts.push_back(top->xf);
-            o = &s->objs[top->child];
+        std::vector<int> chain;
+        for (int guard = 0; s->objs[oi].kind == OBJ_INSTANCE; ++guard) {
+            if (guard > 64) return set_error("pt_world_build: instance chain too deep");
+            chain.push_back((int)insts.size());
+            insts.push_back(s->objs[oi].xf);
+            oi = s->objs[oi].child;
         }
+        for (size_t k = 0; k < chain.size(); ++k) {
+            insts[chain[k]].outer = k == 0 ? -1 : chain[k - 1];
+            insts[chain[k]].inner = k + 1 < chain.size() ? chain[k + 1] : -1;
+        }
+        if (!chain.empty()) inst = chain.front();
+        const HostObj* o = &s->objs[oi];
+        auto to_world = [&](D3 p) {   // object space -> world: innermost instance first
+            for (size_t k = chain.size(); k-- > 0;) {
+                const InstD& m = insts[chain[k]];
+                p = xform_point(d3(m.c0), d3(m.c1), d3(m.c2), d3(m.t), p);
+            }
+            return p;
+        };
         const bool is_light = wi < s->world_lights.size();
         if (is_light) lights.push_back((uint32_t)entries.size());   // any hittable may be a light (world.rs:18-20)
         Entry e{};
@@ -536,54 +558,65 @@ int pt::scene_build(pt_scene* s) {
         case OBJ_MESH: {
             e.kind = ENTRY_MESH;
             if (o->tris.empty()) return set_error("pt_world_build: empty mesh");
-            std::vector<BuildItem> items(o->tris.size());
-            for (size_t i = 0; i < o->tris.size(); ++i) {
-                Box b;
-                b.grow(d3(o->tris[i].v0)); b.grow(d3(o->tris[i].v1)); b.grow(d3(o->tris[i].v2));
-                items[i] = BuildItem{b, b.centroid(), (uint32_t)i};
-                local.grow(b);
+            auto it = blas_of.find(oi);
+            if (it == blas_of.end()) {
+                std::vector<BuildItem> items(o->tris.size());
+                SharedBlas sb;
+                for (size_t i = 0; i < o->tris.size(); ++i) {
+                    Box b;
+                    b.grow(d3(o->tris[i].v0)); b.grow(d3(o->tris[i].v1)); b.grow(d3(o->tris[i].v2));
+                    items[i] = BuildItem{b, b.centroid(), (uint32_t)i};
+                    sb.local.grow(b);
+                }
+                std::vector<uint32_t> perm;
+                sb.tri_base = (uint32_t)tris.size();
+                if ((size_t)sb.tri_base + o->tris.size() > 0x07FFFFFFu) return set_error("pt_world_build: too many triangles");
+                int leaf_max = 4;   // PT_LEAF_MAX: experiments only (smaller leaves were slower on scene 6)
+                if (const char* ev = exp_env("PT_LEAF_MAX")) leaf_max = std::min(8, std::max(1, atoi(ev)));
+                Builder bl{nodes, items, leaf_max, MAX_BLAS_DEPTH, true, &perm, sb.tri_base};
+                Box bb;
+                sb.root = bl.build(0, items.size(), 0, bb);
+                max_blas_depth = std::max(max_blas_depth, bl.depth_reached);
+                sb.extent = box_extent(bb);
+                sb.face_pos.resize(perm.size());
+                for (size_t k = 0; k < perm.size(); ++k) {
+                    const uint32_t face = perm[k];
+                    sb.face_pos[face] = (uint32_t)k;
+                    tris.push_back(o->tris[face]);
+                    tri_gid.push_back(face);                 // face index inside the mesh; the kernels add Entry::first_prim
+                    if (any_attr) tri_attr.push_back(o->tri_attr.empty() ? TriAttr{} : o->tri_attr[face]);
+                }
+                it = blas_of.emplace(oi, std::move(sb)).first;
             }
-            std::vector<uint32_t> perm;
-            const uint32_t tri_base = (uint32_t)tris.size();
-            if ((size_t)tri_base + o->tris.size() > 0x07FFFFFFu) return set_error("pt_world_build: too many triangles");
-            int leaf_max = 4;   // PT_LEAF_MAX: experiments only (smaller leaves were slower on scene 6)
-            if (const char* e = exp_env("PT_LEAF_MAX")) leaf_max = std::min(8, std::max(1, atoi(e)));
-            Builder bl{nodes, items, leaf_max, MAX_BLAS_DEPTH, true, &perm, tri_base};
-            Box bb;
-            e.blas_root = bl.build(0, items.size(), 0, bb);
-            max_blas_depth = std::max(max_blas_depth, bl.depth_reached);
-            e.extent = box_extent(bb);
+            const SharedBlas& sb = it->second;
+            e.blas_root = sb.root;
+            e.extent = sb.extent;
+            local = sb.local;
             const uint32_t flags = PRIM_TRI | (o->has_normals ? PRIM_HAS_NORMALS : 0u) | (o->has_uvs ? PRIM_HAS_UVS : 0u);
-            const uint32_t gid_base = (uint32_t)prims.size();
-            prims.resize(prims.size() + o->tris.size());
-            for (size_t k = 0; k < perm.size(); ++k) {
-                const uint32_t face = perm[k];
-                prims[gid_base + face] = PrimRef{flags, tri_base + (uint32_t)k, (uint32_t)o->mat, inst};
-                tris.push_back(o->tris[face]);
-                tri_gid.push_back(gid_base + face);
-                if (any_attr) tri_attr.push_back(o->tri_attr.empty() ? TriAttr{} : o->tri_attr[face]);
-            }
+            for (size_t face = 0; face < o->tris.size(); ++face)   // one PrimRef per PLACED triangle: ids are per placement
+                prims.push_back(PrimRef{flags, sb.tri_base + sb.face_pos[face], (uint32_t)o->mat, inst});
             break;
         }
         default:
             return set_error("pt_world_build: unsupported object kind");
         }
         e.n_prims = (uint32_t)prims.size() - e.first_prim;
-        Box world = inst >= 0 ? xform_box(local, insts[inst]) : local;
-        if (inst >= 0 && o->kind == OBJ_MESH) {
+        Box world = local;
+        for (size_t k = chain.size(); k-- > 0;) world = xform_box(world, insts[chain[k]]);   // box of the box, per instance (aabb.rs:50-76)
+        if (!chain.empty() && o->kind == OBJ_MESH) {
             // an instanced mesh gets the bounds of its TRANSFORMED VERTICES, not the box of its transformed box
             // (aabb.rs:50-76 does the latter): a mesh turned by ~50 degrees has a third less box to enter, and
             // every ray that enters costs a trip through the mesh pass. Any conservative box gives the same
             // closest hit; store_box pads by 1e-7 relative, far above the rounding of the transform.
             Box tight;
-            const InstD& m = insts[inst];
             for (const TriD& t : o->tris)
-                for (const double* v : {t.v0, t.v1, t.v2}) tight.grow(xform_point(d3(m.c0), d3(m.c1), d3(m.c2), d3(m.t), d3(v)));
+                for (const double* v : {t.v0, t.v1, t.v2}) tight.grow(to_world(d3(v)));
             world = tight;
         }
         tlas_items.push_back(BuildItem{world, world.centroid(), (uint32_t)entries.size()});
         entries.push_back(e);
     }
+    if (prims.size() >= (size_t)HIT_ID_MASK - 4) return set_error("pt_world_build: too many primitives (28-bit ids)");
     for (PrimRef& pr : prims) pr.kind |= (uint32_t)s->mats[pr.mat].kind << PRIM_MAT_KIND_SHIFT;
     std::vector<Box> entry_boxes(tlas_items.size());
     for (const BuildItem& it : tlas_items) entry_boxes[it.ref_payload] = it.box;

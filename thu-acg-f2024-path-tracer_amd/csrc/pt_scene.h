@@ -43,7 +43,9 @@ struct HostObj {
     bool has_normals = false, has_uvs = false;
     int child = -1;                 // instance
     InstD xf{};
-    bool used = false;              // already placed in the world or wrapped by an instance
+    // An object is either placed in the world directly (once) or wrapped by instances — any number of them, and an
+    // instance may wrap an instance (Instance::new takes an Arc<dyn Hittable>, instance.rs:20-30).
+    bool placed = false, wrapped = false;
 };
 
 struct DeviceBuffers {

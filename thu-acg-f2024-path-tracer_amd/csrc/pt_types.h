@@ -42,13 +42,13 @@ struct PrimRef {         // indexed by GLOBAL primitive id (lights list first, t
     uint32_t kind;       // PrimKind | PRIM_HAS_*
     uint32_t index;      // index into spheres[] / quads[] / tris[]
     uint32_t mat;
-    int32_t inst;        // instance transform or -1
+    int32_t inst;        // OUTERMOST instance of the placement's chain, or -1
 };
 struct Entry {           // one per world-level object (lights list first, then objects)
     uint32_t kind;       // EntryKind
     uint32_t first_prim; // global id of its first primitive
-    int32_t inst;
-    uint32_t blas_root;  // node index (ENTRY_MESH)
+    int32_t inst;        // OUTERMOST instance of the placement's chain, or -1
+    uint32_t blas_root;  // node index (ENTRY_MESH); several placements of one mesh share the tree and its triangles
     float extent;        // ENTRY_MESH: max |coordinate| of the mesh's (local-space) BVH boxes
     uint32_t n_prims;    // 1 (sphere, quad), 6 (cuboid) or the triangle count (mesh)
     uint32_t pad[2];
@@ -57,7 +57,13 @@ struct SphereD { double r, p1[3], p2[3]; };
 struct QuadD { double q[3], u[3], v[3], w[3], n[3], d; };
 struct TriD { double v0[3], v1[3], v2[3]; };
 struct TriAttr { double n[3][3]; double uv[3][2]; };   // only when the mesh has them
-struct InstD { double c0[3], c1[3], c2[3], t[3], i0[3], i1[3], i2[3], it[3]; };
+// One Instance of a placement (instance.rs:12-30): forward transform (columns c0..c2, translation t) and its analytic rigid
+// inverse. Instances nest (Instance::new takes any Hittable): a placement is a CHAIN of them — `inner` is the next one
+// towards the object, `outer` the next one towards the world, -1 at the ends. Every placement owns its chain.
+struct InstD {
+    double c0[3], c1[3], c2[3], t[3], i0[3], i1[3], i2[3], it[3];
+    int32_t inner, outer;
+};
 
 // ---- textures / materials ------------------------------------------------------------
 enum TexKind : uint32_t { TEX_SOLID_RGB = 0, TEX_SOLID_F = 1, TEX_CHECKER = 2, TEX_IMAGE = 3 };
@@ -69,6 +75,7 @@ struct TexD {
 };
 enum MatKind : uint32_t { MAT_DIFFUSE = 0, MAT_METAL = 1, MAT_GLASS = 2, MAT_PRINCIPLED = 3, MAT_LIGHT = 4,
                           MAT_SHEEN = 5, MAT_CLEARCOAT = 6, MAT_MIX = 7, MAT_KINDS = 8 };
+constexpr uint32_t CLASS_MISS = 0u, CLASS_IDLE = 1u + MAT_KINDS, CLASS_DEAD = 2u + MAT_KINDS, N_CLASSES = 3u + MAT_KINDS;
 // MAT_SHEEN: p[0..2] = base colour, p[3] = sheen_tint (sheen.rs). MAT_CLEARCOAT: alpha_g (clearcoat.rs).
 // MAT_MIX: p[0] = t, color_tex / rough_tex hold the two child MATERIAL indices (mix.rs; children are leaves).
 struct MatD {
@@ -100,7 +107,7 @@ struct SceneD {
     const QuadD* quads;
     const TriD* tris;
     const TriAttr* tri_attr;     // parallel to tris when any mesh has normals/uvs, else null
-    const uint32_t* tri_gid;     // BLAS-order triangle -> global primitive id
+    const uint32_t* tri_gid;     // BLAS-order triangle -> face index inside its mesh; global id = Entry::first_prim + that (a mesh may be placed several times)
     const InstD* insts;
     const TexD* tex;
     const MatD* mats;
@@ -128,6 +135,12 @@ constexpr uint32_t TLAS_FLAT_MAX = 12;   // measured: 8-10 entries (Cornell, sce
 //          in scene 6 — stay coherent in traversal and in material. Items that fall outside a
 //          ragged image edge are skipped (slot state SLOT_IDLE for one iteration).
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
+// PoolD::hit_prim — what K2 hands to K3, one word per slot: the closest primitive's global id in bits 0..27 (all ones:
+// nothing hit) and in bits 28..31 the CLASS k_shade sorts the slot by, so that K3's classification is ONE coalesced
+// load per slot instead of a chain of three dependent ones (state -> id -> PrimRef): 0 miss, 1 + MatKind of the hit
+// primitive's material, then idle and dead slots (K2 reads the slot state anyway).
+constexpr uint32_t HIT_ID_MASK = 0x0FFFFFFFu, HIT_CLASS_SHIFT = 28;
+constexpr uint32_t HIT_SLOT_IDLE = 0xFFFFFFFEu, HIT_SLOT_DEAD = 0xFFFFFFFDu;   // K2-internal sentinels next to HIT_NONE
 constexpr uint32_t SLOT_DEAD = 0xFFFFFFFFu;   // value of `bounce` for a finished slot
 constexpr uint32_t SLOT_IDLE = 0xFFFFFFFEu;   // dynamic mode: drew an item outside the image, draws again next iteration
 // Path state is kept as two records per slot (array of structures): k_shade visits slots in
@@ -140,9 +153,15 @@ struct alignas(64) RayRec {                       // current ray (direction norm
     double ox, oy, oz, dx, dy, dz, time;
     uint32_t sample, draw;                        // sample index, RNG draw counter
 };
-struct alignas(32) PathRec {
-    double tx, ty, tz;                            // throughput
+#ifndef PT_PATHREC_BYTES
+#define PT_PATHREC_BYTES 64
+#endif
+struct alignas(PT_PATHREC_BYTES) PathRec {        // 64 B: a whole HBM sector per slot, written whole (32-B records made K3 write
+    double tx, ty, tz;                            // half sectors at different times: read-modify-write at the memory side)
     uint32_t pixel, pad;                          // dynamic mode: pixel of the sample in flight
+#if PT_PATHREC_BYTES == 64
+    double reserved[4];
+#endif
 };
 struct PoolD {
     RayRec* ray;

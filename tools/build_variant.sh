@@ -7,9 +7,13 @@ NAME=$1; REV=$2; shift; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 PKG="$ROOT/thu-acg-f2024-path-tracer_amd"
 mkdir -p "$PKG/variants"
-if [ "$REV" = "WORK" ]; then
-  SRC="$PKG"
-  make -C "$SRC" -j4 "$@" > /dev/null
+if [ "$REV" = "WORK" ]; then          # a clean build of the working tree (so that EXTRA=... flags take effect)
+  TMP=$(mktemp -d)
+  mkdir -p "$TMP/thu-acg-f2024-path-tracer_amd"
+  cp -r "$PKG/csrc" "$PKG/host" "$PKG/Makefile" "$TMP/thu-acg-f2024-path-tracer_amd/"
+  cp -r "$ROOT/include" "$TMP/"
+  SRC="$TMP/thu-acg-f2024-path-tracer_amd"
+  make -C "$SRC" -j4 libpt_amd.so "$@" > /dev/null
 else
   TMP=$(mktemp -d)
   git -C "$ROOT" archive "$REV" thu-acg-f2024-path-tracer_amd include | tar -x -C "$TMP"

@@ -10,7 +10,7 @@ orc.set_math_mode(True)
 ctx = pt.Context(0)
 bad = 0
 for sid in range(1, 8):
-    images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt._SCENE_IMAGES.get(sid, [])}
+    images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt.SCENE_IMAGE_FILES.get(sid, [])}
     for width, lo, hi, seed in ((72, 0, 3, 2), (101, 2, 5, 3), (56, 1, 4, 12345678901)):
         gs, os_ = pt.Scene(ctx), orc.Scene()
         gcam, ocam = gs.build_scene(sid, width, hi), os_.build_scene(sid, width, hi, images=images)

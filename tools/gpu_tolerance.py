@@ -11,7 +11,7 @@ import oracle_py as orc
 
 
 def measure(ctx, sid, width, spp, seed=1, det=False):
-    images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt._SCENE_IMAGES.get(sid, [])}
+    images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt.SCENE_IMAGE_FILES.get(sid, [])}
     gs = pt.Scene(ctx); gcam = gs.build_scene(sid, width, spp)
     os_ = orc.Scene(); ocam = os_.build_scene(sid, width, spp, images=images)
     orc.set_math_mode(det)

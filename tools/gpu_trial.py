@@ -7,7 +7,7 @@ pt = importlib.import_module("thu-acg-f2024-path-tracer_amd")
 import oracle_py as orc
 
 def images_for(scene_id):
-    return {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt._SCENE_IMAGES.get(scene_id, [])}
+    return {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt.SCENE_IMAGE_FILES.get(scene_id, [])}
 
 def compare(ctx, scene_id, width, spp, k=1, save=None):
     t = time.time()
