@@ -53,7 +53,9 @@ PT_DEV V3 tex_rgb(const SceneD& sc, int32_t t, double u, double v, V3 p) {
     for (int depth = 0; depth < 16; ++depth) {
         const TexD& T = sc.tex[t];
         if (T.kind == TEX_CHECKER) {
-            t = (int32_t)(checker_is_first(T.inv_scale, p) ? T.t1 : T.t2);
+            const bool first = checker_is_first(T.inv_scale, p);
+            if (T.flat) return first ? V3{T.c1[0], T.c1[1], T.c1[2]} : V3{T.c2[0], T.c2[1], T.c2[2]};
+            t = (int32_t)(first ? T.t1 : T.t2);
             continue;
         }
         if (T.kind == TEX_IMAGE) return tex_image(sc, T, u, v);
@@ -65,7 +67,9 @@ PT_DEV double tex_f(const SceneD& sc, int32_t t, V3 p) {
     for (int depth = 0; depth < 16; ++depth) {
         const TexD& T = sc.tex[t];
         if (T.kind == TEX_CHECKER) {
-            t = (int32_t)(checker_is_first(T.inv_scale, p) ? T.t1 : T.t2);
+            const bool first = checker_is_first(T.inv_scale, p);
+            if (T.flat) return first ? T.c1[0] : T.c2[0];
+            t = (int32_t)(first ? T.t1 : T.t2);
             continue;
         }
         return T.v[0];

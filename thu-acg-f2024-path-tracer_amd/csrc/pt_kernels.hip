@@ -20,6 +20,12 @@
 namespace pt {
 
 constexpr int BLOCK = 256;
+// Resident blocks per CU the batch form of K2 is compiled for. Its register count sits right at the 128-register step
+// (4 waves per SIMD) and tipped over it with unrelated edits elsewhere in this file: measured on one build pair, scene 3's
+// K2 was 10 % faster at four blocks than at three, scene 5's 16 % — so the bound is stated instead of left to chance.
+#ifndef PT_EXTEND_BATCH_BLOCKS
+#define PT_EXTEND_BATCH_BLOCKS 4
+#endif
 
 // K2 writes its result (one primitive id per slot) once and never re-reads it, while the scene tables
 // (BVH, primitives: a few MB) are re-read by every wave: the result leaves with non-temporal stores.
@@ -312,7 +318,7 @@ PT_DEV Closest closest_hit_flat(const SceneD& sc, bool alive, const RayD& r, dou
 // suffers when traversal lengths inside a wave differ a lot (sky ray next to a mesh ray). Used for
 // scenes without meshes (and as the fallback for BVHs deeper than k_extend2's LDS stack).
 template <bool FLAT>   // FLAT: SceneD::tlas_flat (two instantiations so that each keeps its own register budget)
-__global__ __launch_bounds__(BLOCK) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
+__global__ __launch_bounds__(BLOCK, PT_EXTEND_BATCH_BLOCKS) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
     unsigned long long nseg = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
@@ -616,6 +622,11 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     const bool alive = bounce != SLOT_DEAD;
     const bool was_idle = bounce == SLOT_IDLE;
     bool finished = was_idle;
+    // A path that ends on a surface (roulette, sampler returned None, depth bound) would make its whole wave run the
+    // regeneration code — dequeue, camera ray: ~400 instructions — for one or two lanes: with 64 lanes and a few per cent
+    // of such endings per bounce, most surface groups paid for it. Instead the slot is parked as SLOT_IDLE and refilled
+    // next iteration together with the other idle slots, where every lane regenerates (class sort: CLASS_IDLE).
+    bool parked = false;
     uint32_t pixel = 0, sample = 0;
     RayD ray{};
     V3 thr{}, rad{};
@@ -643,7 +654,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             add_radiance(pool, pixel, rad, thr * emission);
             if (bounce > 5) {                                        // russian roulette :190-196
                 double p = clampd(luminance(thr), 0.01, 1.0);
-                if (rng_f64(rng) > p) finished = true;
+                if (rng_f64(rng) > p) finished = parked = true;
                 else thr = thr / p;
             }
             if (!finished) {
@@ -656,7 +667,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
                 if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
                 else ok = mat_sample(sc, m, hit, wo, rng, cam.two_pi_scale, dir);
                 if (!ok) {
-                    finished = true;                                 // :209-211
+                    finished = parked = true;                        // :209-211
                 } else {
                     double bsdf_pdf;
                     V3 brdf;
@@ -668,7 +679,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
                     ray = make_ray(hit.point + e * hit.gn, dir, ray.time);
                     thr = thr * attenuation;
                     ++bounce;
-                    if (bounce >= cam.max_depth) finished = true;    // loop bound :177
+                    if (bounce >= cam.max_depth) finished = parked = true;    // loop bound :177
                 }
             }
         }
@@ -681,7 +692,8 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         // shard has run dry the wave looks at all shards at once (lane i reads shard i) and moves on to the next one
         // that still has items — without this, slots died while other shards still held work and the frame ended
         // on a long, thin tail.
-        unsigned long long need = __ballot(alive && finished);
+        parked = parked && pool.defer_regen != 0u;
+        unsigned long long need = __ballot(alive && finished && !parked);
         while (need) {
             const int leader = __ffsll((long long)need) - 1;
             const bool asking = (need >> lane) & 1ull;
@@ -711,7 +723,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     }
     if (alive && finished) {
         if (!was_idle) ++n_done;
-        if (more && next_idle) {
+        if (parked && pool.dynamic) {
+            bounce = SLOT_IDLE;
+        } else if (more && next_idle) {
             bounce = SLOT_IDLE;
         } else if (more) {
             rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), next_pixel, next_sample, 0u};

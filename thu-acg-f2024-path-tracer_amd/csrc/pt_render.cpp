@@ -261,6 +261,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     pool.spp_begin = spp_begin;
     pool.spp_end = spp_end;
     pool.dynamic = dynamic ? 1u : 0u;
+    pool.defer_regen = (dynamic && !exp_env("PT_NO_DEFER_REGEN")) ? 1u : 0u;
     pool.total_work = total_work;
     pool.width = dc.width;
     pool.height = dc.height;
@@ -328,7 +329,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     timer.end(st);
     uint64_t iterations = 0;
     const uint64_t per_slot = dynamic ? (total_work + n_slots - 1) / std::max<uint64_t>(n_slots, 1) + 1 : (spp + k - 1) / k;
-    const uint64_t max_iterations = per_slot * (uint64_t)std::max(1u, dc.max_depth) + 4;
+    const uint64_t max_iterations = per_slot * ((uint64_t)std::max(1u, dc.max_depth) + 1) + 4;   // + 1: a parked slot idles one iteration
     uint32_t poll_every = 8;
     bool alive = spp != 0 && dc.max_depth != 0;
     if (spp != 0 && dc.max_depth == 0) {

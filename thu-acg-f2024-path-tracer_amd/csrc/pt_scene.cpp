@@ -638,6 +638,13 @@ int pt::scene_build(pt_scene* s) {
             atlas.insert(atlas.end(), s->tex[i].image.begin(), s->tex[i].image.end());
         }
     }
+    for (TexD& t : tex)   // checkers of two solid children carry the children's values
+        if (t.kind == TEX_CHECKER) {
+            const TexD &a = tex[t.t1], &b = tex[t.t2];
+            const bool solid = (a.kind == TEX_SOLID_RGB || a.kind == TEX_SOLID_F) && (b.kind == TEX_SOLID_RGB || b.kind == TEX_SOLID_F);
+            t.flat = solid ? 1u : 0u;
+            for (int c = 0; c < 3; ++c) { t.c1[c] = solid ? a.v[c] : 0.0; t.c2[c] = solid ? b.v[c] : 0.0; }
+        }
     std::vector<float> entry_box(6 * entries.size());   // tlas_items[i] is entry i (built in entry order, before the builder permutes them)
     for (size_t i = 0; i < entry_boxes.size(); ++i) Builder::store_box(entry_boxes[i], &entry_box[6 * i], &entry_box[6 * i + 3]);
     SceneD v{};

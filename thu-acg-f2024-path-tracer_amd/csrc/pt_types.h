@@ -68,10 +68,14 @@ struct InstD {
 // ---- textures / materials ------------------------------------------------------------
 enum TexKind : uint32_t { TEX_SOLID_RGB = 0, TEX_SOLID_F = 1, TEX_CHECKER = 2, TEX_IMAGE = 3 };
 struct TexD {
-    uint32_t kind, t1, t2, w, h, pad;
+    uint32_t kind, t1, t2, w, h;
+    uint32_t flat;       // TEX_CHECKER whose two children are solid: their values sit in c1 / c2 — one level less in the chain of
+                         // DEPENDENT loads primitive -> material -> texture -> child texture (~700 cycles each in k_shade).
+                         // (Also copying the descriptors into the material record made k_shade spill 384 B per lane.)
     uint64_t ofs;        // byte offset into the RGB8 atlas
     double v[3];
     double inv_scale;
+    double c1[3], c2[3];
 };
 enum MatKind : uint32_t { MAT_DIFFUSE = 0, MAT_METAL = 1, MAT_GLASS = 2, MAT_PRINCIPLED = 3, MAT_LIGHT = 4,
                           MAT_SHEEN = 5, MAT_CLEARCOAT = 6, MAT_MIX = 7, MAT_KINDS = 8 };
@@ -153,11 +157,14 @@ struct alignas(64) RayRec {                       // current ray (direction norm
     double ox, oy, oz, dx, dy, dz, time;
     uint32_t sample, draw;                        // sample index, RNG draw counter
 };
+// 32 B. Measured (round 2, -DPT_PATHREC_BYTES=64): padding the record to a whole 64-B sector and writing all of it —
+// so that K3 never writes half sectors — made K3 6 % SLOWER (560 vs 525 ms per 1000-spp frame of scene 6): two more 16-B
+// stores per slot cost more than the partial-sector writes do. The 64-B form stays behind the macro for that measurement.
 #ifndef PT_PATHREC_BYTES
-#define PT_PATHREC_BYTES 64
+#define PT_PATHREC_BYTES 32
 #endif
-struct alignas(PT_PATHREC_BYTES) PathRec {        // 64 B: a whole HBM sector per slot, written whole (32-B records made K3 write
-    double tx, ty, tz;                            // half sectors at different times: read-modify-write at the memory side)
+struct alignas(PT_PATHREC_BYTES) PathRec {
+    double tx, ty, tz;                            // throughput
     uint32_t pixel, pad;                          // dynamic mode: pixel of the sample in flight
 #if PT_PATHREC_BYTES == 64
     double reserved[4];
@@ -176,6 +183,8 @@ struct PoolD {
     uint32_t n_slots, n_pixels, k;                // k = slots per pixel (static mode)
     uint32_t spp_begin, spp_end;
     uint32_t dynamic, n_alloc;                    // n_alloc: slots rounded up to a multiple of 64
+    uint32_t defer_regen, pad_;                   // dynamic mode: a path that ends ON A SURFACE (roulette, sampler, depth) parks its slot
+                                                  // as SLOT_IDLE; it is refilled next iteration among the idle slots (k_shade)
     uint32_t width, height, tiles_x, n_tile_pixels;   // dynamic mode: 8x8 tiling, n_tile_pixels = tiles_x*tiles_y*64
 };
 
