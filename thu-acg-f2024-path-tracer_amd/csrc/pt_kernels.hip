@@ -164,6 +164,33 @@ PT_DEV int visit_node(const BvhNode* nd, const RayF& f, float t_min, float t_max
 }
 PT_DEV float t_max_f32(double t) { return __double2float_ru(t); }   // rounded UP: conservative upper end
 
+// One triangle leaf (<= 8 triangles, BLAS order first .. first+count-1) for the ray of this lane. Two passes: every
+// triangle goes through the division-free screen (tri_screen: all lanes useful), the survivors — the triangles the ray
+// really crosses, rarely more than one per leaf — through the full test. A wave runs the expensive pass as often as its
+// unluckiest lane has survivors (once or twice) instead of `count` times; per-lane early-outs inside ONE pass would buy
+// nothing, the wave would still wait for the lane that goes on. PT_LEAF_SCREEN=0 restores the single pass.
+#ifndef PT_LEAF_SCREEN
+#define PT_LEAF_SCREEN 1
+#endif
+PT_DEV void test_leaf(const SceneD& sc, uint32_t first, uint32_t count, const RayD& r, double t_min, uint32_t first_prim, Closest& best) {
+#if PT_LEAF_SCREEN
+    uint32_t mask = 0;
+    for (uint32_t i = 0; i < count; ++i)
+        if (tri_screen(sc.tris[first + i], r)) mask |= 1u << i;
+    while (mask) {
+        const uint32_t i = first + (uint32_t)(__ffs((int)mask) - 1);
+        mask &= mask - 1u;
+        double t, u, v;
+        if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, first_prim + sc.tri_gid[i]);
+    }
+#else
+    for (uint32_t i = first; i < first + count; ++i) {
+        double t, u, v;
+        if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, first_prim + sc.tri_gid[i]);
+    }
+#endif
+}
+
 // U: `gid` is wave-uniform (the flat top-level walk) -> the primitive's record arrives by scalar loads (ldu)
 template <bool U = false>
 PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint32_t gid, Closest& best) {
@@ -208,10 +235,7 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
             }
         } else if ((cur & REF_TYPE_MASK) == REF_TRIS) {
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
-            for (uint32_t i = first; i < first + count; ++i) {
-                double t, u, v;
-                if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, mesh_first_prim + sc.tri_gid[i]);
-            }
+            test_leaf(sc, first, count, r, t_min, mesh_first_prim, best);
             t_max_f = t_max_f32(best.t);
         } else if ((cur & REF_TYPE_MASK) == REF_ENTRY) {
             const Entry e = sc.entries[cur & 0x3FFFFFFFu];
@@ -384,10 +408,7 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
         }
         if ((cur & REF_TYPE_MASK) != REF_TRIS) break;             // REF_EMPTY: nothing left
         const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
-        for (uint32_t i = first; i < first + count; ++i) {
-            double t, u, v;
-            if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, e.first_prim + sc.tri_gid[i]);
-        }
+        test_leaf(sc, first, count, r, t_min, e.first_prim, best);
         t_max_f = t_max_f32(best.t);
         if (sp == 0) break;
         cur = stk[(--sp) * BLOCK];
@@ -570,10 +591,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 if (busy) {
                     if ((cur & REF_TYPE_MASK) == REF_TRIS) {
                         const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
-                        for (uint32_t i = first; i < first + count; ++i) {
-                            double t, u, v;
-                            if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, first_prim + sc.tri_gid[i]);
-                        }
+                        test_leaf(sc, first, count, r, t_min, first_prim, best);
                         t_max_f = t_max_f32(best.t);
                         cur = sp > 0 ? stk[(--sp) * BLOCK] : REF_EMPTY;
                     }
@@ -937,6 +955,7 @@ typedef void (*extend2_fn)(SceneD, PoolD, CountersD*);
 static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min blocks per CU
     switch (code) {
     case 163: return k_extend2<16, 3>;
+    case 164: return k_extend2<16, 4>;   // experiment: four blocks per CU at 128 registers (84 B of spills)
     case 203: return k_extend2<20, 3>;
     case 242: return k_extend2<24, 2>;
     default: return k_extend2<24, 3>;

@@ -295,7 +295,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         int code = need <= 16 ? 163 : need <= 20 ? 203 : 243;   // three blocks per CU: four would cap the kernel at 128 registers and spill
         if (const char* e = exp_env("PT_EXT2")) {
             const int c = atoi(e);
-            if (c / 10 >= need && (c == 163 || c == 203 || c == 242 || c == 243)) code = c;
+            if (c / 10 >= need && (c == 163 || c == 164 || c == 203 || c == 242 || c == 243)) code = c;
         }
         return code;
     };
