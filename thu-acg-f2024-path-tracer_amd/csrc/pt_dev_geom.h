@@ -88,34 +88,6 @@ PT_DEV bool hit_tri(const TriD& tr, const RayD& r, double t_min, double& t, doub
     return true;
 }
 
-// Division-free screening of hit_tri: false ONLY when hit_tri(tr, r, t_min, ...) returns false, and then with no
-// 1/a (a correctly rounded f64 division is ~15 instructions, two of them quarter-rate) and no t. Same operands and the
-// same operation order as hit_tri up to the products it decides on; the decisions are taken on x = s.h and y = d.q
-// instead of u = fl(fl(1/a) x) and v = fl(fl(1/a) y). With rho = x/a (exact quotient): u = rho (1+e1)(1+e2), |e| <= 2^-53,
-// so u < 0 exactly when rho < 0 (no underflow: guarded by |x| >= 1e-300 |a|), and u > 1 whenever rho > 1 + 2^-51; the
-// constant below leaves 4 ulps for the rounding of the comparison's own product. Same for v, and for fl(u + v) > 1.
-// Everything this lets through is decided by hit_tri itself, so the two-pass leaf test gives hit_tri's result bit for bit.
-PT_DEV bool tri_screen(const TriD& tr, const RayD& r) {
-    V3 v0 = ld3(tr.v0);
-    V3 edge1 = ld3(tr.v1) - v0, edge2 = ld3(tr.v2) - v0;
-    V3 h = cross(r.d, edge2);
-    double a = dot(edge1, h);
-    const double aa = fabs(a);
-    if (aa < 1e-8) return false;                                  // mesh.rs:57-59, the same test
-    const double big = aa * 1.0000000000000018;                   // |a| (1 + 8 ulp)
-    V3 s = r.o - v0;
-    double x = dot(s, h);
-    const double sx = a < 0.0 ? -x : x;                           // x * sign(a): the sign of u
-    if (sx < 0.0 && -sx >= aa * 1e-300) return false;             // u < 0
-    if (sx > big) return false;                                   // u > 1
-    V3 q = cross(s, edge1);
-    double y = dot(r.d, q);
-    const double sy = a < 0.0 ? -y : y;
-    if (sy < 0.0 && -sy >= aa * 1e-300) return false;             // v < 0
-    if (sx >= 0.0 && sy >= 0.0 && sx + sy > big) return false;    // u + v > 1
-    return true;
-}
-
 // hit_info.rs:57-67
 PT_DEV void tangent_basis(V3 n, V3& tangent, V3& bitangent) {
     V3 a = fabs(n.x) > 0.9 ? V3{0.0, 1.0, 0.0} : V3{1.0, 0.0, 0.0};

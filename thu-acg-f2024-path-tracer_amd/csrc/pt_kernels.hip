@@ -164,31 +164,16 @@ PT_DEV int visit_node(const BvhNode* nd, const RayF& f, float t_min, float t_max
 }
 PT_DEV float t_max_f32(double t) { return __double2float_ru(t); }   // rounded UP: conservative upper end
 
-// One triangle leaf (<= 8 triangles, BLAS order first .. first+count-1) for the ray of this lane. Two passes: every
-// triangle goes through the division-free screen (tri_screen: all lanes useful), the survivors — the triangles the ray
-// really crosses, rarely more than one per leaf — through the full test. A wave runs the expensive pass as often as its
-// unluckiest lane has survivors (once or twice) instead of `count` times; per-lane early-outs inside ONE pass would buy
-// nothing, the wave would still wait for the lane that goes on. PT_LEAF_SCREEN=0 restores the single pass.
-#ifndef PT_LEAF_SCREEN
-#define PT_LEAF_SCREEN 1
-#endif
+// One triangle leaf (<= 8 triangles, BLAS order first .. first+count-1) for the ray of this lane.
+// (Tried in round 2 and removed: a two-pass form — a division-free, exactly equivalent screen of every triangle, then
+// the full test for the survivors only, so that a wave runs the expensive pass once or twice instead of `count` times.
+// Bit-exact, but 1.5 % SLOWER on scene 6: the screen repeats two thirds of the test's arithmetic and the full pass still
+// runs once for almost every leaf.)
 PT_DEV void test_leaf(const SceneD& sc, uint32_t first, uint32_t count, const RayD& r, double t_min, uint32_t first_prim, Closest& best) {
-#if PT_LEAF_SCREEN
-    uint32_t mask = 0;
-    for (uint32_t i = 0; i < count; ++i)
-        if (tri_screen(sc.tris[first + i], r)) mask |= 1u << i;
-    while (mask) {
-        const uint32_t i = first + (uint32_t)(__ffs((int)mask) - 1);
-        mask &= mask - 1u;
-        double t, u, v;
-        if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, first_prim + sc.tri_gid[i]);
-    }
-#else
     for (uint32_t i = first; i < first + count; ++i) {
         double t, u, v;
         if (hit_tri(sc.tris[i], r, t_min, t, u, v)) consider(best, t, first_prim + sc.tri_gid[i]);
     }
-#endif
 }
 
 // U: `gid` is wave-uniform (the flat top-level walk) -> the primitive's record arrives by scalar loads (ldu)
@@ -955,10 +940,9 @@ typedef void (*extend2_fn)(SceneD, PoolD, CountersD*);
 static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min blocks per CU
     switch (code) {
     case 163: return k_extend2<16, 3>;
-    case 164: return k_extend2<16, 4>;   // experiment: four blocks per CU at 128 registers (84 B of spills)
-    case 203: return k_extend2<20, 3>;
-    case 242: return k_extend2<24, 2>;
-    default: return k_extend2<24, 3>;
+    case 164: return k_extend2<16, 4>;
+    case 204: return k_extend2<20, 4>;
+    default: return k_extend2<24, 3>;   // 24 stack entries: 43.5 KB of LDS per block, three blocks per CU
     }
 }
 void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int code, hipStream_t st) {   // code: pt_render.cpp extend_code

@@ -292,10 +292,13 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     auto extend2_code = [&]() -> int {
         const int need = (int)s->stack_need_extend2;
         if (need > 24) return 0;
-        int code = need <= 16 ? 163 : need <= 20 ? 203 : 243;   // three blocks per CU: four would cap the kernel at 128 registers and spill
+        // four blocks per CU where the LDS allows it (stacks of 16 and 20 entries): the kernel then runs at 128 registers with
+        // 64 B of spills per lane and is still 7.5 % faster than at three blocks and 149 registers (round 2; in round 1, at
+        // 166 registers, the same bound meant 168 B of spills and lost 11 %)
+        int code = need <= 16 ? 164 : need <= 20 ? 204 : 243;
         if (const char* e = exp_env("PT_EXT2")) {
             const int c = atoi(e);
-            if (c / 10 >= need && (c == 163 || c == 164 || c == 203 || c == 242 || c == 243)) code = c;
+            if (c / 10 >= need && (c == 163 || c == 164 || c == 204 || c == 243)) code = c;
         }
         return code;
     };
