@@ -97,6 +97,12 @@ int pt_world_add_object(pt_scene*, int obj);
 int pt_world_add_light(pt_scene*, int obj);
 int pt_world_build(pt_scene*);          /* build_bvh: flatten to SoA, build BVHs, upload to HBM */
 uint32_t pt_world_prim_count(pt_scene*);
+/* BVH::build (bvh.rs:24-121) for large meshes on the GPU: meshes with at least min_triangles triangles get an LBVH built
+ * by HIP kernels at the next pt_world_build (default 2^19; 0 = always the host's binned-SAH builder). Any conservative
+ * tree gives the same hits; an LBVH is cheaper to build and costlier to traverse. _info: meshes the GPU builder handled
+ * in the last build and the depth of the deepest of them. */
+int pt_world_set_device_bvh_threshold(pt_scene*, uint32_t min_triangles);
+int pt_world_device_bvh_info(pt_scene*, uint32_t* n_meshes, uint32_t* deepest);
 
 /* ---- asset ingest (host): the roles of tobj::load_obj (main.rs:408) and
  * ImageReader::open().decode().to_rgb8() (texture.rs:62-67) for .obj / Radiance .hdr ------- */

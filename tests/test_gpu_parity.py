@@ -662,3 +662,49 @@ def test_shared_and_nested_instances_bit_exact(pt, det, ctx):
     with pytest.raises(pt.PtError, match="already placed"):
         s.instance(i1, (0, 1, 0), 0.1, (0, 0, 0))
     s.close()
+
+
+def test_device_bvh_builder_bit_exact(pt, det, ctx):
+    """pt_world_set_device_bvh_threshold: mesh BVHs built by the GPU LBVH builder (csrc/pt_bvh_device.hip) instead of the host's
+    binned SAH. The closest hit is tree-independent (minimum t, ties -> larger id), so hits, segment counts and every
+    accumulator value must equal the oracle's (its own tree is the reference's sweep SAH) and the host-built scene's."""
+    def build(scene, device):
+        spec = SceneSpec()
+        rgb = lambda r, g, b: spec.add("tex_solid_rgb", r, g, b)
+        spec.add("world_add_object", spec.add("quad", (-8.0, 0.0, -8.0), (0.0, 0.0, 16.0), (16.0, 0.0, 0.0),
+                                              spec.add("mat_diffuse", spec.add("tex_checker", 0.9, rgb(0.2, 0.2, 0.3), rgb(0.9, 0.9, 0.8)), -1)))
+        mats = [spec.add("mat_metal", rgb(0.9, 0.7, 0.5), spec.add("tex_solid_f", 0.1)), spec.add("mat_glass", rgb(1, 1, 1), spec.add("tex_solid_f", 0.02), 0.0, 1.5)]
+        for k, (sub, sc, tr) in enumerate(((4, 0.9, (-1.2, 0.95, 0.0)), (5, 0.8, (1.1, 0.85, 0.6)))):
+            P, I = icosphere(sub)
+            P = (P * (1.0 + 0.15 * np.sin(7.0 * P[:, [0]]) * np.cos(5.0 * P[:, [1]]))).astype(np.float32)      # a lumpy ball
+            m = spec.add("mesh", sc, P, I, None, None, mats[k])
+            spec.add("world_add_object", spec.add("instance", m, (0.3, 1.0, 0.2), 0.4 + k, tr))
+        spec.add("world_add_light", spec.add("quad", (-1.0, 4.0, -1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), spec.add("mat_light", rgb(8, 8, 7))))
+        spec.camera = default_camera(width=72, look_from=(0.0, 1.6, -5.0), look_at=(0.0, 0.8, 0.0), vfov=42.0, env_color=(0.1, 0.12, 0.2))
+        if device is not None:
+            scene.set_device_bvh_threshold(1000 if device else 0)
+        res = spec.replay(scene)
+        scene.world_build()
+        return spec, res
+    gd, gh, os_ = pt.Scene(ctx), pt.Scene(ctx), det.Scene()
+    spec, rd = build(gd, True)
+    _, rh = build(gh, False)
+    _, ro = build(os_, None)
+    n_dev, depth = gd.device_bvh_info()
+    assert n_dev == 2 and 8 <= depth <= 20, (n_dev, depth)
+    assert gh.device_bvh_info()[0] == 0
+    cam_d, cam_h, cam_o = spec.make_camera(pt.Camera, rd), spec.make_camera(pt.Camera, rh), spec.make_camera(det.Camera, ro)
+    ad, sd = gd.render(cam_d, 4, 0, 6, slots_per_pixel=1)
+    ah, sh = gh.render(cam_h, 4, 0, 6, slots_per_pixel=1)
+    ao, cnt = os_.render(cam_o, 4, 0, 6)
+    assert sd.segments == sh.segments == cnt["segments"]
+    np.testing.assert_array_equal(ad, ao)
+    np.testing.assert_array_equal(ah, ao)
+    rng = np.random.default_rng(12)
+    rays = np.zeros((5000, 7))
+    rays[:, 0:3] = rng.uniform(-2.5, 2.5, (5000, 3)) + (0.0, 2.0, 0.0)
+    rays[:, 3:6] = rng.normal(size=(5000, 3))
+    g = gd.intersect(rays)
+    np.testing.assert_array_equal(g, os_.intersect(rays))
+    assert (g[:, 0] > 0).mean() > 0.4
+    gd.close(); gh.close(); os_.close()

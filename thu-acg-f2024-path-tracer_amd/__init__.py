@@ -91,6 +91,7 @@ ABI_SYMBOLS = [
     "pt_mat_diffuse", "pt_mat_metal", "pt_mat_glass", "pt_mat_principled", "pt_mat_light", "pt_mat_mix", "pt_mat_sheen", "pt_mat_clearcoat",
     "pt_sphere", "pt_quad", "pt_cuboid", "pt_mesh", "pt_instance",
     "pt_world_add_object", "pt_world_add_light", "pt_world_build", "pt_world_prim_count",
+    "pt_world_set_device_bvh_threshold", "pt_world_device_bvh_info",
     "pt_load_obj", "pt_load_obj_single_index", "pt_load_hdr_rgb8", "pt_load_png_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
     "pt_build_scene", "pt_camera_init", "pt_render", "pt_resolve_u8", "pt_intersect", "pt_math_probe",
     "pt_shard_range", "pt_comm_create", "pt_comm_destroy", "pt_comm_rank", "pt_comm_world", "pt_comm_barrier", "pt_comm_allreduce_f64",
@@ -139,6 +140,9 @@ def _load():
     lib.pt_world_build.argtypes = [C.c_void_p]
     lib.pt_world_prim_count.argtypes = [C.c_void_p]
     lib.pt_world_prim_count.restype = C.c_uint32
+    if hasattr(lib, "pt_world_set_device_bvh_threshold"):
+        lib.pt_world_set_device_bvh_threshold.argtypes = [C.c_void_p, C.c_uint32]
+        lib.pt_world_device_bvh_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pt_register_image.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.pt_find_registered_image.argtypes = [C.c_void_p, C.c_char_p]
     lib.pt_save_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -321,6 +325,15 @@ class Scene:
     def world_add_light(self, obj): return _check(lib.pt_world_add_light(self.handle, obj), "world_add_light")
     def world_build(self): return _check(lib.pt_world_build(self.handle), "world_build")
     def prim_count(self) -> int: return lib.pt_world_prim_count(self.handle)
+
+    def set_device_bvh_threshold(self, min_triangles: int):
+        """Meshes with at least this many triangles get their BVH built on the GPU at the next world_build (0 = never)."""
+        _check(lib.pt_world_set_device_bvh_threshold(self.handle, min_triangles), "pt_world_set_device_bvh_threshold")
+
+    def device_bvh_info(self):
+        n, d = C.c_uint32(), C.c_uint32()
+        _check(lib.pt_world_device_bvh_info(self.handle, C.byref(n), C.byref(d)), "pt_world_device_bvh_info")
+        return n.value, d.value
 
     def register_image(self, name: str, img: np.ndarray):
         img = np.ascontiguousarray(img, dtype=np.uint8)

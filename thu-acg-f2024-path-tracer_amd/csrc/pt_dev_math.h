@@ -141,18 +141,33 @@ PT_DEV V3 xform_point(const double* c0, const double* c1, const double* c2, cons
 struct Rng {
     uint32_t seed_lo, seed_hi, pixel, sample, draw;
 };
-PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                          uint32_t out[4]) {
+// One Philox4x32-10 block. Two things about its cost on this chip: (1) a 32-bit integer multiply is a quarter-rate
+// instruction and the textbook round needs four of them (mulhi + mullo, twice) — written as two 64-bit products the
+// compiler emits ONE v_mad_u64_u32 per product, halving the multiplies (the round-1 form was 22 % of k_shade's issue
+// time: ~8 blocks per sample x 40 quarter-rate multiplies); (2) inlined at every draw site the block appeared 41 times
+// in k_shade — as a real function (PT_PHILOX_CALL) it is there once.
+struct PhiloxOut {
+    uint32_t x, y, z, w;
+};
+#ifndef PT_PHILOX_INLINE
+#define PT_PHILOX_CALL __device__ __noinline__
+#else
+#define PT_PHILOX_CALL __device__ __forceinline__
+#endif
+PT_PHILOX_CALL PhiloxOut philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0;
-        uint32_t h1 = __umulhi(M1, c2), l1 = M1 * c2;
-        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += W0; k1 += W1;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    return PhiloxOut{c0, c1, c2, c3};
+}
+PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const PhiloxOut o = philox_block(c0, c1, c2, c3, k0, k1);
+    out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = o.w;
 }
 PT_DEV uint64_t rng_u64(Rng& r) {
     uint32_t o[4];

@@ -1,5 +1,6 @@
 // Scene builder + flattener + BVH builder (host). See pt_scene.h.
 #include "pt_scene.h"
+#include "pt_bvh_device.h"
 #include "pt_detmath.h"
 
 #include <hip/hip_runtime.h>
@@ -296,6 +297,18 @@ static int place(pt_scene* s, int obj, std::vector<int>& list, const char* who) 
 extern "C" int pt_world_add_object(pt_scene* s, int obj) { return place(s, obj, s->world_objects, "pt_world_add_object"); }
 extern "C" int pt_world_add_light(pt_scene* s, int obj) { return place(s, obj, s->world_lights, "pt_world_add_light"); }
 extern "C" uint32_t pt_world_prim_count(pt_scene* s) { return s->n_prims; }
+extern "C" int pt_world_set_device_bvh_threshold(pt_scene* s, uint32_t min_triangles) {
+    if (!s) return set_error("pt_world_set_device_bvh_threshold: null scene");
+    s->device_bvh_min_tris = min_triangles;
+    s->built = false;
+    return 0;
+}
+extern "C" int pt_world_device_bvh_info(pt_scene* s, uint32_t* n_meshes, uint32_t* deepest) {
+    if (!s || !s->built) return set_error("pt_world_device_bvh_info: world not built");
+    if (n_meshes) *n_meshes = s->n_device_blas;
+    if (deepest) *deepest = s->device_blas_depth;
+    return 0;
+}
 extern "C" int pt_world_build(pt_scene* s) { return scene_build(s); }
 
 // ----------------------------------------------------------------------------------------
@@ -500,6 +513,7 @@ int pt::scene_build(pt_scene* s) {
     order.insert(order.end(), s->world_objects.begin(), s->world_objects.end());
     if (order.empty()) return set_error("pt_world_build: the world is empty");
     int max_blas_depth = 0;
+    s->n_device_blas = s->device_blas_depth = 0;
     struct SharedBlas {   // one tree and one triangle range per MESH OBJECT, however many placements it has
         uint32_t root, tri_base;
         float extent;
@@ -573,10 +587,36 @@ int pt::scene_build(pt_scene* s) {
                 if ((size_t)sb.tri_base + o->tris.size() > 0x07FFFFFFu) return set_error("pt_world_build: too many triangles");
                 int leaf_max = 4;   // PT_LEAF_MAX: experiments only (smaller leaves were slower on scene 6)
                 if (const char* ev = exp_env("PT_LEAF_MAX")) leaf_max = std::min(8, std::max(1, atoi(ev)));
-                Builder bl{nodes, items, leaf_max, MAX_BLAS_DEPTH, true, &perm, sb.tri_base};
-                Box bb;
-                sb.root = bl.build(0, items.size(), 0, bb);
-                max_blas_depth = std::max(max_blas_depth, bl.depth_reached);
+                Box bb = sb.local;
+                bool on_device = false;
+                if (s->device_bvh_min_tris != 0 && o->tris.size() >= s->device_bvh_min_tris) {
+                    // large mesh: LBVH on the GPU (pt_bvh_device.hip); a tree too deep for the traversal stacks falls back
+                    DeviceBlas db;
+                    const double lo[3] = {sb.local.lo.x, sb.local.lo.y, sb.local.lo.z}, hi[3] = {sb.local.hi.x, sb.local.hi.y, sb.local.hi.z};
+                    if (build_blas_device(o->tris.data(), (uint32_t)o->tris.size(), lo, hi, (uint32_t)leaf_max, (uint32_t)MAX_BLAS_DEPTH, db, s->ctx->stream)) {
+                        const uint32_t node_base = (uint32_t)nodes.size();
+                        auto fix = [&](uint32_t ref) {
+                            if ((ref & REF_TYPE_MASK) == REF_NODE) return REF_NODE | (node_base + ref);
+                            return (ref & ~0x07FFFFFFu) | (sb.tri_base + (ref & 0x07FFFFFFu));     // REF_TRIS: count bits kept
+                        };
+                        for (BvhNode nd : db.nodes) {
+                            nd.child0 = fix(nd.child0);
+                            nd.child1 = fix(nd.child1);
+                            nodes.push_back(nd);
+                        }
+                        sb.root = REF_NODE | node_base;
+                        perm = db.order;
+                        max_blas_depth = std::max(max_blas_depth, db.depth);
+                        ++s->n_device_blas;
+                        s->device_blas_depth = std::max<uint32_t>(s->device_blas_depth, (uint32_t)db.depth);
+                        on_device = true;
+                    }
+                }
+                if (!on_device) {
+                    Builder bl{nodes, items, leaf_max, MAX_BLAS_DEPTH, true, &perm, sb.tri_base};
+                    sb.root = bl.build(0, items.size(), 0, bb);
+                    max_blas_depth = std::max(max_blas_depth, bl.depth_reached);
+                }
                 sb.extent = box_extent(bb);
                 sb.face_pos.resize(perm.size());
                 for (size_t k = 0; k < perm.size(); ++k) {
@@ -663,7 +703,9 @@ int pt::scene_build(pt_scene* s) {
     v.n_entries = (uint32_t)entries.size();
     v.n_prims = (uint32_t)prims.size();
     v.n_lights = (uint32_t)lights.size();
-    v.tlas_flat = entries.size() <= TLAS_FLAT_MAX && !exp_env("PT_NO_FLAT_TLAS") ? 1u : 0u;
+    uint32_t flat_max = TLAS_FLAT_MAX;
+    if (const char* ev = exp_env("PT_FLAT_MAX")) flat_max = (uint32_t)atoi(ev);
+    v.tlas_flat = entries.size() <= flat_max && !exp_env("PT_NO_FLAT_TLAS") ? 1u : 0u;
     s->stack_need_extend2 = v.tlas_flat ? (uint32_t)(max_blas_depth + 1) : s->stack_need;
     dev.view = v;
     s->n_prims = v.n_prims;

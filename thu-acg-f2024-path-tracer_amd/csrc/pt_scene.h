@@ -67,6 +67,8 @@ struct pt_scene {
     uint32_t n_prims = 0;
     uint32_t n_mesh_entries = 0;   // world-level triangle meshes (picks the K2 variant)
     uint32_t stack_need = 0;       // worst-case traversal stack entries of this scene's BVHs
+    uint32_t device_bvh_min_tris = 1u << 19;   // meshes with at least this many triangles get their BVH built on the GPU (0 = never)
+    uint32_t n_device_blas = 0, device_blas_depth = 0;   // meshes of the last build that the GPU builder handled, deepest of them
     uint32_t stack_need_extend2 = 0;   // ... for k_extend2, whose top-level walk is stackless when the entry list is walked flat
     pt::DeviceBuffers dev;
     // path pool cache (re-used across pt_render calls of the same size)
