@@ -184,10 +184,10 @@ def test_slot_layouts_and_sample_ranges_agree(pt, det, ctx):
     gs.close()
 
 
-@pytest.mark.parametrize("n_meshes,flat", [(7, True), (20, False)])
+@pytest.mark.parametrize("n_meshes,flat", [(7, True), (30, False)])
 def test_mesh_crowd_bit_exact(pt, det, ctx, n_meshes, flat):
     """K2's rarely taken paths: a frame filled by overlapping mesh instances — rays that enter more than four
-    mesh boxes (the fifth is walked on the spot), windows whose candidate list (768) overflows, and, with 20
+    mesh boxes (the fifth is walked on the spot), windows whose candidate list (768) overflows, and, with 30
     world entries, the per-lane walk of the top-level TREE instead of the flat entry list."""
     rng = np.random.default_rng(42 + n_meshes)
     spec = SceneSpec()

@@ -246,13 +246,34 @@ PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uin
     return best;
 }
 
-// dynamic mode: work item -> (pixel, sample); false when the item lies outside a ragged image edge
-PT_DEV bool work_to_pixel(const PoolD& pool, unsigned long long w, uint32_t& pixel, uint32_t& sample) {
-    const uint32_t in_frame = (uint32_t)(w % pool.n_tile_pixels);
-    sample = pool.spp_begin + (uint32_t)(w / pool.n_tile_pixels);
+// floor(a / b) and a - b * floor(a / b) for a < 2^53, 0 < b < 2^31, by ONE f64 division and an exact integer correction.
+// (The compiler's inline expansion of a 64-bit unsigned division is ~100 instructions, a third of them quarter-rate
+// integer multiplies, and it ran once per regenerated camera ray.)
+PT_DEV void divmod_u53(unsigned long long a, uint32_t b, unsigned long long& q, uint32_t& r) {
+    unsigned long long q0 = (unsigned long long)((double)a / (double)b);     // within 1 of the true quotient
+    long long rem = (long long)(a - q0 * (unsigned long long)b);
+    if (rem < 0) { --q0; rem += (long long)b; }
+    else if (rem >= (long long)b) { ++q0; rem -= (long long)b; }
+    q = q0;
+    r = (uint32_t)rem;
+}
+PT_DEV void divmod_u31(uint32_t a, uint32_t b, uint32_t& q, uint32_t& r) {   // a, b < 2^31: the f64 quotient floors exactly
+    q = (uint32_t)((double)a / (double)b);
+    r = a - q * b;
+}
+// dynamic mode: work item -> (pixel, sample) and the pixel's row / column; false when the item lies outside a ragged image edge
+PT_DEV bool work_to_pixel(const PoolD& pool, unsigned long long w, uint32_t& pixel, uint32_t& sample, uint32_t& row, uint32_t& col) {
+    unsigned long long q;
+    uint32_t in_frame;
+    divmod_u53(w, pool.n_tile_pixels, q, in_frame);
+    sample = pool.spp_begin + (uint32_t)q;
     const uint32_t tile = in_frame >> 6, in_tile = in_frame & 63u;
-    const uint32_t x = (tile % pool.tiles_x) * 8u + (in_tile & 7u), y = (tile / pool.tiles_x) * 8u + (in_tile >> 3);
+    uint32_t ty, tx;
+    divmod_u31(tile, pool.tiles_x, ty, tx);
+    const uint32_t x = tx * 8u + (in_tile & 7u), y = ty * 8u + (in_tile >> 3);
     pixel = y * pool.width + x;
+    row = y;
+    col = x;
     return x < pool.width && y < pool.height;
 }
 // shard-local counter value -> global work item: 64-item chunks are dealt round-robin to the shards
@@ -263,16 +284,17 @@ PT_DEV unsigned long long shard_item(unsigned long long c, uint32_t shard) {
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t seed) {
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
-        uint32_t pixel, sample;
+        uint32_t pixel, sample, row = 0, col = 0;
         bool has_work;
         bool idle = false;
         if (pool.dynamic) {   // initial work items 0 .. n_slots-1 (the host starts the shard counters there)
             has_work = s < pool.n_slots && (unsigned long long)s < pool.total_work;
-            idle = has_work && !work_to_pixel(pool, s, pixel, sample);
+            idle = has_work && !work_to_pixel(pool, s, pixel, sample, row, col);
             if (!has_work || idle) { pixel = 0; sample = 0; }
         } else {
             pixel = s % pool.n_pixels;
             sample = pool.spp_begin + s / pool.n_pixels;
+            divmod_u31(pixel, cam.width, row, col);
             has_work = s < pool.n_slots && sample < pool.spp_end;
             pool.ax[s] = 0.0; pool.ay[s] = 0.0; pool.az[s] = 0.0;
             pool.rx[s] = 0.0; pool.ry[s] = 0.0; pool.rz[s] = 0.0;
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
             continue;
         }
         Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, 0u};
-        RayD r = generate_ray(cam, pixel / cam.width, pixel % cam.width, rng);
+        RayD r = generate_ray(cam, row, col, rng);
         store_ray(pool, s, r, sample, rng.draw);
         pool.bounce[s] = 0;
     }
@@ -618,9 +640,28 @@ PT_DEV void add_radiance(const PoolD& pool, uint32_t pixel, V3& rad, V3 c) {
     }
 }
 
+#ifdef PT_STAMPS
+// Diagnostic build: where a k_shade wave spends its cycles (s_memtime ticks; MI355X_MICROARCH.md "In-kernel stamps"). The stamp
+// after the record loads forces vmcnt(0) so that the first segment is the pure fetch wait. Never part of the product build.
+PT_DEV unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__shared__ unsigned long long g_prof[N_CLASSES + 1][8];
+#define PT_STAMP(i) const unsigned long long t_##i = stamp()
+#define PT_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PT_STAMP(i)
+#define PT_DRAIN()
+#endif
+
 // `enable` = false makes the lane a bystander that only takes part in the wave ballots.
 PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane, bool enable,
                        uint32_t& shard, unsigned long long& n_done, unsigned long long& n_died) {
+    PT_STAMP(0);
     uint32_t bounce = enable ? pool.bounce[s] : SLOT_DEAD;
     const bool alive = bounce != SLOT_DEAD;
     const bool was_idle = bounce == SLOT_IDLE;
@@ -634,6 +675,15 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     RayD ray{};
     V3 thr{}, rad{};
     Rng rng{};
+#ifdef PT_STAMPS
+    uint32_t prof_class = was_idle ? CLASS_IDLE : CLASS_DEAD;
+    if (alive && !was_idle) prof_class = pool.hit_prim[s] >> HIT_CLASS_SHIFT;
+    prof_class = (uint32_t)__builtin_amdgcn_readfirstlane((int)prof_class);
+    uint32_t d_draw = 0;
+    if (alive && !was_idle) { thr = load_path(pool, s, pixel); ray = load_ray(pool, s, sample, d_draw); }
+    PT_DRAIN();
+#endif
+    PT_STAMP(1);
     if (alive && !was_idle) {
         uint32_t draw;
         thr = load_path(pool, s, pixel);
@@ -687,8 +737,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             }
         }
     }
+    PT_STAMP(2);
     // ---- finished paths: accumulate (camera.rs:107) and regenerate in place -----------------
-    uint32_t next_pixel = pixel, next_sample = 0;
+    uint32_t next_pixel = pixel, next_sample = 0, next_row = 0, next_col = 0;
     bool more = false, next_idle = false;
     if (pool.dynamic) {
         // K5: wave ballot + prefix popcount, ONE atomic per wave on the wave's shard of the work counter. When the
@@ -707,7 +758,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
                 const unsigned long long w = shard_item(base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull)), shard);
                 if (w < pool.total_work) {
                     more = true;
-                    next_idle = !work_to_pixel(pool, w, next_pixel, next_sample);
+                    next_idle = !work_to_pixel(pool, w, next_pixel, next_sample, next_row, next_col);
                 }
             }
             need = __ballot(asking && !more);
@@ -724,6 +775,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         next_sample = sample + pool.k;
         more = next_sample < pool.spp_end;
     }
+    PT_STAMP(3);
     if (alive && finished) {
         if (!was_idle) ++n_done;
         if (parked && pool.dynamic) {
@@ -732,7 +784,8 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             bounce = SLOT_IDLE;
         } else if (more) {
             rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), next_pixel, next_sample, 0u};
-            ray = generate_ray(cam, next_pixel / cam.width, next_pixel % cam.width, rng);
+            if (!pool.dynamic) divmod_u31(next_pixel, cam.width, next_row, next_col);
+            ray = generate_ray(cam, next_row, next_col, rng);
             thr = V3{1.0, 1.0, 1.0};
             rad = V3{0.0, 0.0, 0.0};
             bounce = 0;
@@ -751,6 +804,18 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             if (!pool.dynamic) { pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z; }
         }
     }
+#ifdef PT_STAMPS
+    PT_DRAIN();
+    PT_STAMP(4);
+    if (lane == 0) {   // block-local sums in LDS (global atomics here would themselves be what the next group waits for)
+        atomicAdd(&g_prof[prof_class][0], 1ull);
+        atomicAdd(&g_prof[prof_class][1], t_1 - t_0);
+        atomicAdd(&g_prof[prof_class][2], t_2 - t_1);
+        atomicAdd(&g_prof[prof_class][3], t_3 - t_2);
+        atomicAdd(&g_prof[prof_class][4], t_4 - t_3);
+        atomicAdd(&g_prof[prof_class][5], t_4 - t_0);
+    }
+#endif
 }
 
 constexpr int SORT_WINDOW = 2048;   // slots sorted together by k_shade<true, *>
@@ -765,6 +830,10 @@ template <bool SORT, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     unsigned long long n_done = 0, n_died = 0;
     const int lane = (int)(threadIdx.x & 63u);
+#ifdef PT_STAMPS
+    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * 8; i += BLOCK) (&g_prof[0][0])[i] = 0ull;
+    __syncthreads();
+#endif
     uint32_t shard = blockIdx.x % WORK_SHARDS;   // work-counter shard this wave draws from (wave-uniform; moves on when it runs dry)
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_extend = 0;
     if (!SORT) {
@@ -781,6 +850,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
         __shared__ uint32_t s_win;
         const uint32_t n_windows = pool.n_alloc / SORT_WINDOW;
         for (;;) {
+            PT_STAMP(w0);
             if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_shade, 1ull); s_next = 0; }
             __syncthreads();
             if (s_win >= n_windows) break;
@@ -835,6 +905,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             }
             __syncthreads();
             const uint32_t n_live = SORT_WINDOW - s_hist[K_DEAD];
+            PT_STAMP(w1);
             for (;;) {
                 uint32_t g = 0;
                 if (lane == 0) g = atomicAdd(&s_next, 1u);
@@ -846,11 +917,26 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 const uint32_t q = ((n_live + 63u) / 64u - 1u - g) * 64u + (uint32_t)lane;
                 shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[q < n_live ? q : 0u], lane, q < n_live, shard, n_done, n_died);
             }
+            PT_STAMP(w2);
             __syncthreads();   // LDS is reused by the next window
+#ifdef PT_STAMPS
+            PT_STAMP(w3);
+            if (lane == 0) {
+                atomicAdd(&g_prof[N_CLASSES][0], 1ull);
+                atomicAdd(&g_prof[N_CLASSES][1], t_w1 - t_w0);     // window draw + classification + sort
+                atomicAdd(&g_prof[N_CLASSES][2], t_w2 - t_w1);     // shading groups
+                atomicAdd(&g_prof[N_CLASSES][3], t_w3 - t_w2);     // waiting for the block's other waves
+            }
+#endif
         }
     }
     if (n_done) atomicAdd(&cnt->samples, n_done);
     if (n_died) atomicSub(&cnt->alive, n_died);
+#ifdef PT_STAMPS
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * 8; i += BLOCK)
+        if ((&g_prof[0][0])[i]) atomicAdd(&cnt->prof[0][0] + i, (&g_prof[0][0])[i]);
+#endif
 }
 
 // accum[p*3+c] += sum over the k slots of pixel p, in slot order (k == 1: the exact

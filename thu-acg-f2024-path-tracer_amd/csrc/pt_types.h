@@ -123,7 +123,8 @@ struct SceneD {
     const float* entry_box;      // lo[3], hi[3] per entry: its world-space box, padded and rounded outward like the node boxes
     uint32_t tlas_flat;          // n_entries <= TLAS_FLAT_MAX: K2 walks the entry list instead of the top-level tree
 };
-constexpr uint32_t TLAS_FLAT_MAX = 12;   // measured: 8-10 entries (Cornell, scene 6) -26 % / -7 % K2 time, 17 entries (scene 5) +20 %
+constexpr uint32_t TLAS_FLAT_MAX = 24;   // round 1 (vector loads): 8-10 entries -26 % / -7 % K2 time, 17 entries (scene 5) +20 % -> limit 12;
+                                          // round 2 (scalar loads, ldu): 17 entries -20 % -> limit raised
 
 // ---- path pool (one slot per resident path) --------------------------------------------
 // Two work-assignment modes:
@@ -202,6 +203,9 @@ struct CountersD {
     // kernel zeroes the OTHER kernel's queue; the two alternate on one stream.
     unsigned long long win_extend, win_shade;
     unsigned long long pad[11];
+    // diagnostic builds only (-DPT_STAMPS, tools/build_variant.sh): wave-cycle sums per k_shade class
+    // [class][0 groups, 1 record-load wait, 2 body, 3 work dequeue, 4 regeneration + stores, 5 whole], [N_CLASSES][..] = window phases
+    unsigned long long prof[N_CLASSES + 1][8];
     struct alignas(128) Shard { unsigned long long next; unsigned long long pad[15]; } work[WORK_SHARDS];
 };
 
