@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -28,6 +30,25 @@ struct pt_comm {
     double* d_scratch = nullptr;     // small device buffer for host-value collectives
     double* d_accum = nullptr;       // frame accumulator of pt_render_multi (grown on demand)
     size_t accum_bytes = 0;
+};
+
+// RCCL prints a version banner ("RCCL version : ...", five lines) on STDOUT when the first communicator of a process is
+// created. A host that reports its result on stdout (bench.py prints ONE JSON line) must not find it there: while the
+// communicator is being created stdout is pointed at stderr, and whatever the C library buffered is flushed there.
+struct StdoutToStderr {
+    int saved;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) {
+            (void)dup2(saved, 1);
+            close(saved);
+        }
+    }
 };
 
 static bool nccl_ok(ncclResult_t r, const char* what) {
@@ -81,6 +102,7 @@ extern "C" int pt_comm_create(pt_ctx* ctx, int rank, int world, const char* id_p
     if (world < 1 || rank < 0 || rank >= world) return set_error("pt_comm_create: rank/world out of range");
     if (world > 1 && (!id_path || !*id_path)) return set_error("pt_comm_create: a rendezvous path is needed for world > 1");
     if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return -1;
+    StdoutToStderr quiet;   // until this function returns
     ncclUniqueId id;
     memset(&id, 0, sizeof id);
     if (rank == 0 && !nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId")) return -1;

@@ -178,13 +178,31 @@ PT_DEV V3 sample_dielectric(V3 v, V3 h, double eta_i, double eta_o, Rng& rng) { 
     return t;
 }
 
+// The texture values a material's sample / pdf / eval read (base colour, roughness; texture.rs `value`), fetched ONCE,
+// up front: k_shade keeps every global-memory read of a bounce in its first phase so that the pure arithmetic that
+// follows — sample, pdf, eval, next ray — can hide the asynchronous fetch of the wave's next group of path records.
+// The reference looks the same textures up again in each of sample / pdf / eval with the same arguments: same values.
+struct TexVals {
+    V3 color;
+    double rough;
+};
+PT_DEV TexVals fetch_tex(const SceneD& sc, const MatD& m, const HitD& h) {
+    TexVals tv{V3{0.0, 0.0, 0.0}, 0.0};
+    const uint32_t k = m.kind;
+    if (k == MAT_DIFFUSE || k == MAT_METAL || k == MAT_PRINCIPLED || k == MAT_LIGHT) tv.color = tex_rgb(sc, m.color_tex, h.u, h.v, h.point);
+    if (k == MAT_METAL || k == MAT_GLASS) tv.rough = tex_f(sc, m.rough_tex, h.point);
+    return tv;   // MAT_MIX: its children fetch their own (mat_sample / mat_pdf_eval)
+}
+
 // ---- BxDFMaterial::sample (bsdf/mod.rs:23) ----------------------------------------------
 // wo = -ray.direction. Returns false where the reference returns None.
-PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, Rng& rng, double two_pi_scale, V3& dir) {
+PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, Rng& rng, double two_pi_scale, const TexVals& tv, V3& dir) {
     const MatD* leaf = &mat;
+    double rough = tv.rough;
     if (mat.kind == MAT_MIX) {   // mix.rs:25-32: the selector is drawn first, then the chosen child samples
         double p = rng_f64(rng);
         leaf = &sc.mats[mat.p[0] < p ? mat.color_tex : mat.rough_tex];
+        if (leaf->kind == MAT_METAL || leaf->kind == MAT_GLASS) rough = tex_f(sc, leaf->rough_tex, h.point);
     }
     const MatD& m = *leaf;
     switch (m.kind) {
@@ -196,7 +214,6 @@ PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, 
     case MAT_METAL: {     // metal.rs:39-54
         Frame f = frame_to_z(h.sn);
         V3 v = to_local(f, wo);
-        double rough = tex_f(sc, m.rough_tex, h.point);
         V3 hv = ggx_sample_microfacet_normal(v, rough, rng);
         V3 d = to_world(f, reflect(-v, hv));
         if (dot(d, h.sn) <= 0.0) return false;
@@ -206,7 +223,6 @@ PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, 
     case MAT_GLASS: {     // glass.rs:66-90
         Frame f = frame_to_z(h.sn);
         V3 v = to_local(f, wo);
-        double rough = tex_f(sc, m.rough_tex, h.point);
         V3 hv = ggx_sample_microfacet_normal(v, rough, rng);
         double eta_i = h.front ? 1.0 : m.ior, eta_o = h.front ? m.ior : 1.0;
         dir = to_world(f, sample_dielectric(v, hv, eta_i, eta_o, rng));
@@ -261,12 +277,12 @@ PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, 
 }
 
 // ---- BxDFMaterial::pdf + eval (cosine included in eval) -----------------------------------
-PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, double& pdf, V3& brdf) {
+PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, const TexVals& tv, double& pdf, V3& brdf) {
     switch (m.kind) {
     case MAT_DIFFUSE: {   // diffuse.rs:56-65
         Frame f = frame_to_z(h.sn);
         V3 l = to_local(f, wi);
-        V3 color = tex_rgb(sc, m.color_tex, h.u, h.v, h.point);
+        V3 color = tv.color;
         pdf = fabs(l.z) / D_PI;
         brdf = fabs(l.z) * (color / D_PI);
         return;
@@ -275,8 +291,8 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
         Frame f = frame_to_z(h.sn);
         V3 v = to_local(f, wo), l = to_local(f, wi);
         V3 hv = normalize(v + l);
-        double rough = tex_f(sc, m.rough_tex, h.point);
-        V3 base = tex_rgb(sc, m.color_tex, h.u, h.v, h.point);
+        double rough = tv.rough;
+        V3 base = tv.color;
         double g1v = ggx_G1(v, rough), d = ggx_D(hv, rough);
         double pdf_h = g1v * fabs(dot(v, hv)) * d / fabs(v.z);
         pdf = pdf_h * (1.0 / (4.0 * fabs(dot(l, hv))));
@@ -291,7 +307,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
         bool is_reflect = l.z * v.z > 0.0;
         double eta_i = h.front ? 1.0 : m.ior, eta_o = h.front ? m.ior : 1.0;
         V3 hv = generalized_half(v, l, is_reflect, eta_i, eta_o);
-        double rough = tex_f(sc, m.rough_tex, h.point);
+        double rough = tv.rough;
         double g1v = ggx_G1(v, rough), d = ggx_D(hv, rough);
         double pdf_h = g1v * fabs(dot(v, hv)) * d / fabs(v.z);
         double fr = fresnel_dielectric(v, hv, eta_i, eta_o);
@@ -308,7 +324,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
                      specular_tint = m.p[4], ior = m.p[5], sheen = m.p[7], sheen_tint = m.p[8];
         double eta_i = h.front ? 1.0 : ior, eta_o = h.front ? ior : 1.0;
         V3 hv = generalized_half(v, l, is_reflect, eta_i, eta_o);
-        V3 base = tex_rgb(sc, m.color_tex, h.u, h.v, h.point);
+        V3 base = tv.color;
         double acc_pdf = 0.0;
         V3 acc{0.0, 0.0, 0.0};
         const double d = ggx_D(hv, roughness), g1v = ggx_G1(v, roughness);
@@ -388,7 +404,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
 }
 // BxDFMaterial::pdf + eval incl. MixBxDf (mix.rs:34-44): (1-t)*child1 + t*child2. One non-unrolled loop
 // so that the leaf code above is instantiated once.
-PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, double& pdf, V3& brdf) {
+PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, const TexVals& tv, double& pdf, V3& brdf) {
     const bool mix = m.kind == MAT_MIX;
     const int n = mix ? 2 : 1;
     pdf = 0.0;
@@ -398,7 +414,8 @@ PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, 
         const MatD& lm = mix ? sc.mats[c == 0 ? m.color_tex : m.rough_tex] : m;
         double pc;
         V3 fc;
-        leaf_pdf_eval(sc, lm, h, wo, wi, pc, fc);
+        const TexVals ltv = mix ? fetch_tex(sc, lm, h) : tv;
+        leaf_pdf_eval(sc, lm, h, wo, wi, ltv, pc, fc);
         if (!mix) {
             pdf = pc;
             brdf = fc;

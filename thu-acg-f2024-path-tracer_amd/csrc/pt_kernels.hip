@@ -658,87 +658,164 @@ __shared__ unsigned long long g_prof[N_CLASSES + 1][8];
 #define PT_DRAIN()
 #endif
 
-// `enable` = false makes the lane a bystander that only takes part in the wave ballots.
-PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane, bool enable,
-                       uint32_t& shard, unsigned long long& n_done, unsigned long long& n_died) {
-    PT_STAMP(0);
-    uint32_t bounce = enable ? pool.bounce[s] : SLOT_DEAD;
+// ---- path records of one slot as k_shade consumes them -------------------------------------------------------------
+struct SlotIn {
+    uint32_t bounce, hw, pixel, sample, draw;   // state, K2's result word, pixel (dynamic mode), sample index, RNG draw counter
+    V3 thr;
+    RayD ray;
+};
+// straight from the pool (first group of a window, static mode, unsorted K3). `enable` = false: bystander lane.
+PT_DEV SlotIn load_slot_global(const PoolD& pool, uint32_t s, bool enable) {
+    SlotIn in{};
+    in.bounce = enable ? pool.bounce[s] : SLOT_DEAD;
+    if (in.bounce < SLOT_IDLE) {
+        in.thr = load_path(pool, s, in.pixel);
+        in.ray = load_ray(pool, s, in.sample, in.draw);
+        in.hw = pool.hit_prim[s];
+    }
+    return in;
+}
+// Asynchronous fetch of a group's records into the wave's LDS staging area: `global_load_lds` (LDS-DMA) — the data goes
+// from HBM to LDS without passing through (or occupying) a single vector register, which is the only way this kernel, at its
+// 256-register limit, can have the NEXT group's 6.5 KB in flight while it computes on the current one. Layout: chunk c of
+// lane l at stage[c][l] (lane-linear, as the instruction writes: M0 base + lane * size): RayRec = chunks 0..3, PathRec = 4..5,
+// chunk 6 = result words (64 x 4 B) then states (64 x 4 B). Must be executed by ALL 64 lanes (wave-uniform control flow).
+constexpr int STAGE_CHUNKS = 7;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+PT_DEV void stage_fetch(const PoolD& pool, uint32_t s, uint4 (*stage)[64]) {
+    const char* r = reinterpret_cast<const char*>(&pool.ray[s]);
+    const char* p = reinterpret_cast<const char*>(&pool.path[s]);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(r), (lds_ptr)&stage[0][0], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(r + 16), (lds_ptr)&stage[1][0], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(r + 32), (lds_ptr)&stage[2][0], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(r + 48), (lds_ptr)&stage[3][0], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(p), (lds_ptr)&stage[4][0], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(p + 16), (lds_ptr)&stage[5][0], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)&pool.hit_prim[s], (lds_ptr)&stage[6][0], 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)&pool.bounce[s], (lds_ptr)&stage[6][16], 4, 0, 0);
+}
+// the staged records of this lane (after the issuing wave's s_waitcnt vmcnt(0): nothing else orders an LDS read behind an LDS-DMA)
+PT_DEV SlotIn load_slot_stage(const uint4 (*stage)[64], int lane, bool enable) {
+    SlotIn in{};
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(&stage[6][0]);
+    in.bounce = enable ? words[64 + lane] : SLOT_DEAD;
+    in.hw = words[lane];
+    const uint4 a = stage[0][lane], b = stage[1][lane], c = stage[2][lane], d = stage[3][lane], e = stage[4][lane], f = stage[5][lane];
+    auto f64 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
+    in.ray = RayD{V3{f64(a.x, a.y), f64(a.z, a.w), f64(b.x, b.y)}, V3{f64(b.z, b.w), f64(c.x, c.y), f64(c.z, c.w)}, f64(d.x, d.y)};
+    in.sample = d.z;
+    in.draw = d.w;
+    in.thr = V3{f64(e.x, e.y), f64(e.z, e.w), f64(f.x, f.y)};
+    in.pixel = f.z;
+    return in;
+}
+struct NoPrefetch {
+    PT_DEV void operator()() const {}
+};
+
+// K3: the body of camera.rs:177-226 for the path in slot `s`, executed by all 64 lanes of a wave together (it contains
+// wave-level ballots for the work-counter dequeue, K5). `in` = the slot's records; in.bounce == SLOT_DEAD makes the lane
+// a bystander that only takes part in the ballots.
+// Phases, separated by WAVE-UNIFORM points at which `prefetch()` — the asynchronous fetch of the wave's next group of
+// records — may be issued exactly once:
+//   A  everything that reads global memory: hit reconstruction, environment lookup, material record, texture values
+//   -- P1 (a lane of the wave hit a surface, scene without lights): the arithmetic of B hides the fetch
+//   B1 roulette, direction (lights.sample reads the lights' records: scenes with lights prefetch at P1b, after it)
+//   B2 pdf, eval, throughput, next ray — pure arithmetic
+//   C  work dequeue (a RETURNING atomic: its wait would also wait for a fetch issued before it) -- P2 (nothing hit)
+//   D  regeneration (arithmetic), stores
+// vmcnt counts loads, stores, atomics and LDS-DMA in issue order, so a fetch can only hide behind a stretch in which no
+// younger load is waited for — hence the phase discipline (tex values fetched up front, pt_dev_bsdf.h fetch_tex).
+template <class Prefetch>
+PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane, const SlotIn& in,
+                       uint32_t& shard, unsigned long long& n_done, unsigned long long& n_died, Prefetch&& prefetch) {
+    PT_STAMP(1);
+    uint32_t bounce = in.bounce;
     const bool alive = bounce != SLOT_DEAD;
     const bool was_idle = bounce == SLOT_IDLE;
+    const bool live = alive && !was_idle;
     bool finished = was_idle;
     // A path that ends on a surface (roulette, sampler returned None, depth bound) would make its whole wave run the
     // regeneration code — dequeue, camera ray: ~400 instructions — for one or two lanes: with 64 lanes and a few per cent
     // of such endings per bounce, most surface groups paid for it. Instead the slot is parked as SLOT_IDLE and refilled
     // next iteration together with the other idle slots, where every lane regenerates (class sort: CLASS_IDLE).
     bool parked = false;
-    uint32_t pixel = 0, sample = 0;
-    RayD ray{};
-    V3 thr{}, rad{};
+    uint32_t pixel = in.pixel, sample = in.sample;
+    RayD ray = in.ray;
+    V3 thr = in.thr, rad{};
     Rng rng{};
 #ifdef PT_STAMPS
     uint32_t prof_class = was_idle ? CLASS_IDLE : CLASS_DEAD;
-    if (alive && !was_idle) prof_class = pool.hit_prim[s] >> HIT_CLASS_SHIFT;
+    if (live) prof_class = in.hw >> HIT_CLASS_SHIFT;
     prof_class = (uint32_t)__builtin_amdgcn_readfirstlane((int)prof_class);
-    uint32_t d_draw = 0;
-    if (alive && !was_idle) { thr = load_path(pool, s, pixel); ray = load_ray(pool, s, sample, d_draw); }
-    PT_DRAIN();
 #endif
-    PT_STAMP(1);
-    if (alive && !was_idle) {
-        uint32_t draw;
-        thr = load_path(pool, s, pixel);
+    // ---- phase A: all global-memory reads of the bounce -------------------------------------------------------------
+    bool is_hit = false;
+    HitD hit{};
+    const MatD* mp = nullptr;
+    TexVals tv{};
+    if (live) {
         if (!pool.dynamic) {
             pixel = s % pool.n_pixels;
             rad = V3{pool.rx[s], pool.ry[s], pool.rz[s]};
         }
-        ray = load_ray(pool, s, sample, draw);
-        rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, draw};
-        const uint32_t hw = pool.hit_prim[s];
-        const uint32_t gid = hw & HIT_ID_MASK;
-        HitD hit;
-        if ((hw >> HIT_CLASS_SHIFT) == CLASS_MISS || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
+        rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, in.draw};
+        const uint32_t gid = in.hw & HIT_ID_MASK;
+        if ((in.hw >> HIT_CLASS_SHIFT) == CLASS_MISS || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
             add_radiance(pool, pixel, rad, thr * sample_environment(sc, cam, ray.d));   // camera.rs:180-183
             finished = true;
         } else {
-            const MatD& m = sc.mats[hit.mat];
+            is_hit = true;
+            mp = &sc.mats[hit.mat];
+            tv = fetch_tex(sc, *mp, hit);
             // camera.rs:186-187 — added for every material (zero unless emissive) so that a
             // non-finite throughput poisons the sample exactly as it does in the reference
-            V3 emission = m.kind == MAT_LIGHT ? tex_rgb(sc, m.color_tex, hit.u, hit.v, hit.point) : V3{0.0, 0.0, 0.0};
+            V3 emission = mp->kind == MAT_LIGHT ? tv.color : V3{0.0, 0.0, 0.0};
             add_radiance(pool, pixel, rad, thr * emission);
-            if (bounce > 5) {                                        // russian roulette :190-196
-                double p = clampd(luminance(thr), 0.01, 1.0);
-                if (rng_f64(rng) > p) finished = parked = true;
-                else thr = thr / p;
-            }
-            if (!finished) {
-                const double p_light = sc.n_lights == 0 ? 0.0 : 0.5;   // :199-200
-                const double p_bsdf = 1.0 - p_light;
-                const V3 wo = -ray.d;
-                double rsel = rng_f64(rng);
-                V3 dir;
-                bool ok = true;
-                if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
-                else ok = mat_sample(sc, m, hit, wo, rng, cam.two_pi_scale, dir);
-                if (!ok) {
-                    finished = parked = true;                        // :209-211
-                } else {
-                    double bsdf_pdf;
-                    V3 brdf;
-                    mat_pdf_eval(sc, m, hit, wo, dir, bsdf_pdf, brdf);
-                    double light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
-                    double pdf = p_bsdf * bsdf_pdf + p_light * light_pdf;
-                    V3 attenuation = brdf / pdf;
-                    double e = 1e-3 * signum(dot(dir, hit.gn));      // :217-222
-                    ray = make_ray(hit.point + e * hit.gn, dir, ray.time);
-                    thr = thr * attenuation;
-                    ++bounce;
-                    if (bounce >= cam.max_depth) finished = parked = true;    // loop bound :177
-                }
-            }
         }
     }
+    const bool any_hit = __ballot(is_hit) != 0ull;
+    bool fetched = false;                                              // wave-uniform
+    if (any_hit && sc.n_lights == 0u) { prefetch(); fetched = true; }  // P1
+    // ---- phase B1: roulette and the next direction ------------------------------------------------------------------------
+    const double p_light = sc.n_lights == 0 ? 0.0 : 0.5;               // :199-200
+    const double p_bsdf = 1.0 - p_light;
+    const V3 wo = -ray.d;
+    V3 dir{};
+    bool have_dir = false;
+    if (is_hit) {
+        if (bounce > 5) {                                              // russian roulette :190-196
+            double p = clampd(luminance(thr), 0.01, 1.0);
+            if (rng_f64(rng) > p) finished = parked = true;
+            else thr = thr / p;
+        }
+        if (!finished) {
+            double rsel = rng_f64(rng);
+            bool ok = true;
+            if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
+            else ok = mat_sample(sc, *mp, hit, wo, rng, cam.two_pi_scale, tv, dir);
+            if (!ok) finished = parked = true;                         // :209-211
+            else have_dir = true;
+        }
+    }
+    if (any_hit && !fetched) { prefetch(); fetched = true; }           // P1b
+    // ---- phase B2: pdf, eval, throughput, next ray (arithmetic only; lights.pdf reads through the scalar cache) -----------------
+    if (have_dir) {
+        double bsdf_pdf;
+        V3 brdf;
+        mat_pdf_eval(sc, *mp, hit, wo, dir, tv, bsdf_pdf, brdf);
+        double light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
+        double pdf = p_bsdf * bsdf_pdf + p_light * light_pdf;
+        V3 attenuation = brdf / pdf;
+        double e = 1e-3 * signum(dot(dir, hit.gn));                    // :217-222
+        ray = make_ray(hit.point + e * hit.gn, dir, ray.time);
+        thr = thr * attenuation;
+        ++bounce;
+        if (bounce >= cam.max_depth) finished = parked = true;         // loop bound :177
+    }
     PT_STAMP(2);
-    // ---- finished paths: accumulate (camera.rs:107) and regenerate in place -----------------
+    // ---- phase C: finished paths accumulate (camera.rs:107) and draw their next work item ------------------------------------
     uint32_t next_pixel = pixel, next_sample = 0, next_row = 0, next_col = 0;
     bool more = false, next_idle = false;
     if (pool.dynamic) {
@@ -764,10 +841,10 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             need = __ballot(asking && !more);
             if (need) {
                 static_assert(WORK_SHARDS == 64, "one lane per shard");
-                const unsigned long long live = __ballot(shard_item(cnt->work[lane].next, (uint32_t)lane) < pool.total_work);
-                if (live == 0ull) break;                                       // the frame's sample budget is handed out
-                const unsigned long long above = live & ~((2ull << shard) - 1ull);   // next live shard after this one, cyclically
-                shard = (uint32_t)(__ffsll((long long)(above ? above : live)) - 1);
+                const unsigned long long live_shards = __ballot(shard_item(cnt->work[lane].next, (uint32_t)lane) < pool.total_work);
+                if (live_shards == 0ull) break;                                       // the frame's sample budget is handed out
+                const unsigned long long above = live_shards & ~((2ull << shard) - 1ull);   // next live shard after this one, cyclically
+                shard = (uint32_t)(__ffsll((long long)(above ? above : live_shards)) - 1);
             }
         }
     } else if (alive && finished) {
@@ -775,7 +852,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         next_sample = sample + pool.k;
         more = next_sample < pool.spp_end;
     }
+    if (!fetched) prefetch();                                          // P2: behind the dequeue, in front of the regeneration arithmetic
     PT_STAMP(3);
+    // ---- phase D: regeneration in place, stores -----------------------------------------------------------------------------
     if (alive && finished) {
         if (!was_idle) ++n_done;
         if (parked && pool.dynamic) {
@@ -805,20 +884,21 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         }
     }
 #ifdef PT_STAMPS
-    PT_DRAIN();
     PT_STAMP(4);
     if (lane == 0) {   // block-local sums in LDS (global atomics here would themselves be what the next group waits for)
         atomicAdd(&g_prof[prof_class][0], 1ull);
-        atomicAdd(&g_prof[prof_class][1], t_1 - t_0);
         atomicAdd(&g_prof[prof_class][2], t_2 - t_1);
         atomicAdd(&g_prof[prof_class][3], t_3 - t_2);
         atomicAdd(&g_prof[prof_class][4], t_4 - t_3);
-        atomicAdd(&g_prof[prof_class][5], t_4 - t_0);
+        atomicAdd(&g_prof[prof_class][5], t_4 - t_1);
     }
 #endif
 }
 
 constexpr int SORT_WINDOW = 2048;   // slots sorted together by k_shade<true, *>
+#ifndef PT_K3_PREFETCH
+#define PT_K3_PREFETCH 1            // 0: every group's records straight from the pool (the round-1 form), for A/B
+#endif
 
 // K3 launcher kernel. SORT = false: blocks walk the pool in 256-slot chunks, lane i shades slot i.
 // SORT = true (default): a block draws a WINDOW of 2048 slots from a queue, counting-sorts their indices
@@ -838,13 +918,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_extend = 0;
     if (!SORT) {
         // n_alloc is a multiple of 256: whole waves run every chunk (wave ballots inside shade_slot)
-        for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK)
-            shade_slot(sc, cam, pool, cnt, seed, base + threadIdx.x, lane, true, shard, n_done, n_died);
+        for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK) {
+            const uint32_t s = base + threadIdx.x;
+            const SlotIn in = load_slot_global(pool, s, true);
+            shade_slot(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, NoPrefetch{});
+        }
     } else {
         __shared__ uint16_t s_perm[SORT_WINDOW];
         constexpr uint32_t NCLASS = N_CLASSES, K_DEAD = CLASS_DEAD;   // miss, one per material kind, idle, dead
         __shared__ uint32_t s_cnt[NCLASS][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
         __shared__ uint32_t s_hist[NCLASS], s_next;
+        __shared__ uint4 s_stage[BLOCK / 64][STAGE_CHUNKS][64];   // 28 KB: one staging area per wave (stage_fetch)
         constexpr int PER = SORT_WINDOW / BLOCK, NGRP = SORT_WINDOW / 64;
         const int wave = (int)(threadIdx.x >> 6);
         __shared__ uint32_t s_win;
@@ -906,16 +990,62 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             __syncthreads();
             const uint32_t n_live = SORT_WINDOW - s_hist[K_DEAD];
             PT_STAMP(w1);
-            for (;;) {
+            // groups are taken from the END of the sorted order: the expensive classes (principled, glass) sort
+            // last, and starting with them keeps the four waves level when the window runs out (the cheap
+            // misses fill the gaps). Lanes past n_live in the top group are bystanders.
+            const uint32_t n_groups = (n_live + 63u) / 64u;
+            auto grab = [&]() -> uint32_t {                          // this wave's next group of the window (wave-uniform)
                 uint32_t g = 0;
                 if (lane == 0) g = atomicAdd(&s_next, 1u);
-                g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-                if (g * 64u >= n_live) break;
-                // groups are taken from the END of the sorted order: the expensive classes (principled, glass) sort
-                // last, and starting with them keeps the four waves level when the window runs out (the cheap
-                // misses fill the gaps). Lanes past n_live in the top group are bystanders.
-                const uint32_t q = ((n_live + 63u) / 64u - 1u - g) * 64u + (uint32_t)lane;
-                shade_slot(sc, cam, pool, cnt, seed, wbase + s_perm[q < n_live ? q : 0u], lane, q < n_live, shard, n_done, n_died);
+                return (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            };
+            auto slot_of = [&](uint32_t g, bool& enable) -> uint32_t {
+                const uint32_t q = (n_groups - 1u - g) * 64u + (uint32_t)lane;
+                enable = q < n_live;
+                return wbase + s_perm[enable ? q : 0u];
+            };
+            // The wave's next group is reserved and its records requested (LDS-DMA, stage_fetch) from inside shade_slot, at the
+            // point where the current group's arithmetic can hide the fetch; the first group of a window comes straight from
+            // the pool. Dynamic mode only (the static mode's extra per-slot arrays are not staged).
+            const bool use_stage = PT_K3_PREFETCH && pool.dynamic != 0u;
+            uint4 (*stage)[64] = s_stage[wave];
+            uint32_t g = grab();
+            bool staged = false;
+            while (g < n_groups) {
+                PT_STAMP(0);
+                bool enable;
+                const uint32_t s = slot_of(g, enable);
+                SlotIn in;
+                if (staged) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed (and this wave's older stores with it)
+                    in = load_slot_stage(stage, lane, enable);
+                } else {
+                    in = load_slot_global(pool, s, enable);
+                }
+                PT_DRAIN();
+#ifdef PT_STAMPS
+                PT_STAMP(ld);
+                if (lane == 0) atomicAdd(&g_prof[N_CLASSES][5], t_ld - t_0);   // record wait (load or staged), all classes
+#endif
+                uint32_t g_next = n_groups;
+                bool staged_next = false;
+                auto prefetch = [&]() {
+                    g_next = grab();
+                    if (use_stage && g_next < n_groups) {
+                        bool en;
+                        const uint32_t sn = slot_of(g_next, en);
+                        __builtin_amdgcn_sched_barrier(0);            // nothing of the current group's loads may sink below the DMA
+                        stage_fetch(pool, sn, stage);
+                        __builtin_amdgcn_sched_barrier(0);
+                        staged_next = true;
+                    }
+                };
+                shade_slot(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, prefetch);
+#ifdef PT_STAMPS
+                if (lane == 0) atomicAdd(&g_prof[N_CLASSES][4], 1ull);
+#endif
+                g = g_next;
+                staged = staged_next;
             }
             PT_STAMP(w2);
             __syncthreads();   // LDS is reused by the next window

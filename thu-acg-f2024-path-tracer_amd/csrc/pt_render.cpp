@@ -377,7 +377,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         static const char* names[N_CLASSES + 1] = {"miss", "diffuse", "metal", "glass", "principled", "light", "sheen", "clearcoat", "mix", "idle", "dead", "WINDOW"};
         for (uint32_t c = 0; c <= N_CLASSES; ++c) {
             const unsigned long long* p = s->h_counters->prof[c];
-            if (p[0]) fprintf(stderr, "[pt prof] %-10s n %10llu  load %8.0f  body %8.0f  dequeue %8.0f  regen+store %8.0f  whole %8.0f (cycles per wave-group; WINDOW: sort / shade / wait)\n", names[c],
+            if (p[0]) fprintf(stderr, "[pt prof] %-10s n %10llu  load %8.0f  body %8.0f  dequeue %8.0f  regen+store %8.0f  whole %8.0f (cycles per wave-group; WINDOW row: n windows, sort / shade / barrier wait per window, then groups and summed record-wait cycles)\n", names[c],
                               p[0], (double)p[1] / p[0], (double)p[2] / p[0], (double)p[3] / p[0], (double)p[4] / p[0], (double)p[5] / p[0]);
         }
     }
