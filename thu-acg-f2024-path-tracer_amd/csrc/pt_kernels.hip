@@ -895,7 +895,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
 #endif
 }
 
-constexpr int SORT_WINDOW = 2048;   // slots sorted together by k_shade<true, *>
+constexpr int SORT_WINDOW = 2048;   // slots sorted together by k_shade<true, *> (8 x 4-bit class keys per thread: do not enlarge without widening `keys`)
 #ifndef PT_K3_PREFETCH
 #define PT_K3_PREFETCH 1            // 0: every group's records straight from the pool (the round-1 form), for A/B
 #endif
