@@ -182,6 +182,9 @@ def demo_block_stats(scene_id, rgb8):
 MIS_ALBEDO, MIS_EMISSION = (0.8, 0.6, 0.4), (6.0, 5.0, 4.0)
 MIS_QUAD = ((-0.5, 2.0, -0.5), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
 MIS_SPHERE = ((0.0, 2.0, 0.0), 0.4)
+MIS_TRI = ((0.9, 2.0, -0.4), (1.9, 2.0, 0.1), (1.0, 2.0, 0.8))          # the one-triangle mesh light of the two-light scene
+MIS_TRI_EMISSION = (3.0, 6.0, 9.0)
+MIS_QUAD2 = ((-1.6, 2.0, -0.5), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0))           # the quad, moved aside so that the two never overlap in direction
 MIS_CAM = dict(width=24, aspect=1.0, vfov=50.0, look_from=(0.0, 1.0, 0.0), look_at=(0.0, 0.0, 0.0), vup=(0.0, 0.0, 1.0), focal_length=1.0)
 
 
@@ -192,6 +195,10 @@ def mis_scene(light):
     lm = s.add("mat_light", s.add("tex_solid_rgb", *MIS_EMISSION))
     if light == "quad":
         s.add("world_add_light", s.add("quad", *MIS_QUAD, lm))
+    elif light == "two":
+        s.add("world_add_light", s.add("quad", *MIS_QUAD2, lm))
+        lt = s.add("mat_light", s.add("tex_solid_rgb", *MIS_TRI_EMISSION))
+        s.add("world_add_light", s.add("mesh", 1.0, np.array(MIS_TRI, dtype=np.float32), np.array([0, 1, 2], dtype=np.uint32), None, None, lt))
     else:
         s.add("world_add_light", s.add("sphere", MIS_SPHERE[1], MIS_SPHERE[0], MIS_SPHERE[0], lm))
     s.add("world_build")
@@ -214,6 +221,11 @@ def mis_expected(light):
     pts = pts + np.array([0.0, 1e-3, 0.0])          # the second segment starts EPS above the surface (camera.rs:217-222)
     if light == "quad":
         est = true = R.quad_light_floor_radiance(pts, MIS_ALBEDO, MIS_EMISSION, *MIS_QUAD)
+    elif light == "two":
+        tri = [np.array(p, dtype=np.float32).astype(np.float64) for p in MIS_TRI]      # the mesh stores f32 positions
+        q, u, v = (np.asarray(a, float) for a in MIS_QUAD2)
+        lights = [dict(kind="quad", verts=[q, q + u, q + u + v, q + v], emission=MIS_EMISSION), dict(kind="tri", verts=tri, emission=MIS_TRI_EMISSION)]
+        est, true = R.coplanar_lights_floor_radiance(pts - np.array([0.0, 1e-3, 0.0]), MIS_ALBEDO, lights)   # it offsets the segment itself
     else:
         est, true = R.sphere_light_floor_radiance(pts, MIS_ALBEDO, MIS_EMISSION, *MIS_SPHERE)
     shape = (H, W, len(off), 3)

@@ -192,3 +192,128 @@ def sphere_light_floor_radiance(points, albedo, emission, center, radius, n_alph
         est[i] = alb / math.pi * Le * k_est
         true[i] = alb / math.pi * Le * k_true
     return est, true
+
+
+def _tri_rule(n):
+    """Centroid rule on n^2 congruent sub-triangles as barycentric coordinates (m, 3); every node has weight area / n^2."""
+    b = []
+    for i in range(n):
+        for j in range(n - i):
+            b.append(((i + 1 / 3) / n, (j + 1 / 3) / n))
+            if j < n - i - 1:
+                b.append(((i + 2 / 3) / n, (j + 2 / 3) / n))
+    b = np.array(b)
+    return np.concatenate([1.0 - b.sum(axis=1, keepdims=True), b], axis=1)
+
+
+def _ccw(poly):
+    p = np.asarray(poly, float)
+    x, y = p[:, 0], p[:, 1]
+    return p if np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y) > 0 else p[::-1]
+
+
+def _clip_convex(subject, clip):
+    """Sutherland-Hodgman: the part of the convex polygon `subject` inside the convex CCW polygon `clip` ((k, 2), may be empty)."""
+    out = [tuple(p) for p in subject]
+    for k in range(len(clip)):
+        a, b = clip[k], clip[(k + 1) % len(clip)]
+        if not out:
+            break
+        side = lambda p: (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+        src, out = out, []
+        for m in range(len(src)):
+            p, q = src[m], src[(m + 1) % len(src)]
+            sp, sq = side(p), side(q)
+            if sp >= 0:
+                out.append(p)
+            if (sp > 0 and sq < 0) or (sp < 0 and sq > 0):
+                t = sp / (sp - sq)
+                out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+    return np.array(out).reshape(-1, 2)
+
+
+def _poly_nodes(poly, rule):
+    """Quadrature nodes (m, 2) and weights (m,) of a convex polygon: fan of triangles, `rule` on each."""
+    nodes, weights = [], []
+    for k in range(1, len(poly) - 1):
+        tri = np.stack([poly[0], poly[k], poly[k + 1]])
+        area = 0.5 * abs((tri[1, 0] - tri[0, 0]) * (tri[2, 1] - tri[0, 1]) - (tri[1, 1] - tri[0, 1]) * (tri[2, 0] - tri[0, 0]))
+        if area > 0:
+            nodes.append(rule @ tri)
+            weights.append(np.full(len(rule), area / len(rule)))
+    if not nodes:
+        return np.zeros((0, 2)), np.zeros(0)
+    return np.concatenate(nodes), np.concatenate(weights)
+
+
+def coplanar_lights_floor_radiance(points, albedo, lights, eps=1e-3, n_big=28, n_strip=10):
+    """E[reference estimator] at points of a Lambert floor (y = 0, normal +y) under a lights list of flat emitters lying
+    in ONE horizontal plane y = h, max_depth = 2 (trace(), camera.rs:170-228). `lights`: dicts {"kind": "quad"|"tri",
+    "verts": the quad's 4 corners in order | the triangle's 3 vertices, "emission": rgb}.
+
+    What the reference does at the floor hit x0:
+      * with probability 1/2 HittableList::sample picks ONE light uniformly (list.rs:78-84); Quad::sample is uniform on
+        the quad (quad.rs:80-86); Triangle::sample draws u, v uniform in [0,1]^2, w = 1 - u - v (mesh.rs:122-129): the
+        point is uniform over the PARALLELOGRAM of the two edges, half of it (the "outer" half O) outside the triangle;
+      * the claimed pdf is 1/2 cos/pi + 1/2 MEAN over the lights of their pdf (list.rs:86-96), each dist^2 / (cos_l area)
+        where the ray from x0 meets that light (quad.rs:88-98, mesh.rs:131-141 — the triangle claims its OWN area, twice
+        the sampler's density);
+      * the next segment starts at x0 + EPS n, not at x0 (camera.rs:217-222), with the SAME direction: it meets the plane
+        at  x0_h + (1 - EPS/h)(hp - x0_h)  when the direction from x0 aims at hp. So the emitter is reached iff hp lies in
+        the emitter scaled by 1/(1 - EPS/h) about x0_h, a polygon E' that differs from the emitter E by strips EPS/h wide.
+        Where E' sticks out of E the claimed light pdf is 0 and the weight is brdf / (pdf_bsdf / 2) = 2 albedo: rare for
+        cosine-sampled directions, but the triangle's sampler puts half its points in O, right across the long edge — a
+        +2.4 % share at the test's geometry, which is why it has to be modelled (the wide-spread emitters of the other
+        tests lose and gain ~1e-4 there).
+    With g = cos_x cos_l / r^2 and, on a cell c of the plane, claimed density C_c and sampler density S_c (per area):
+        E = albedo/pi * Le_i * [ integral over E'_i of g  +  sum over cells of integral over (E'_i ^ cell) of g (ratio_c - 1) ],
+        ratio_c = (p_b/2 + S_c r^2/cos_l / (2n)) / (p_b/2 + C_c r^2/cos_l / (2n)),   p_b = cos_x / pi,  n = number of lights.
+    Cells: a quad (C = S = 1/A: ratio 1, nothing to add), a triangle T (C = 1/A_t, S = 1/(2 A_t)), its outer half O
+    (C = 0, S = 1/(2 A_t)). Returns (expected, the true integral = the first term)."""
+    P = np.asarray(points, float).reshape(-1, 3)
+    alb = np.asarray(albedo, float)
+    h = float(np.asarray(lights[0]["verts"], float)[0][1])
+    n_l = len(lights)
+    big, strip = _tri_rule(n_big), _tri_rule(n_strip)
+    emit, cells = [], []
+    for L in lights:
+        V = np.asarray(L["verts"], float)
+        assert np.all(V[:, 1] == h), "all emitters in one horizontal plane"
+        V2 = V[:, [0, 2]]
+        if L["kind"] == "quad":
+            emit.append(_ccw(V2))
+        else:
+            A = 0.5 * abs((V2[1, 0] - V2[0, 0]) * (V2[2, 1] - V2[0, 1]) - (V2[1, 1] - V2[0, 1]) * (V2[2, 0] - V2[0, 0]))
+            emit.append(_ccw(V2))
+            cells.append((_ccw(V2), 1.0 / A, 0.5 / A, big))
+            cells.append((_ccw(np.stack([V2[1], V2[1] + V2[2] - V2[0], V2[2]])), 0.0, 0.5 / A, strip))
+
+    def kernel(x0, nodes):
+        d = np.stack([nodes[:, 0] - x0[0], np.full(len(nodes), h - x0[1]), nodes[:, 1] - x0[2]], axis=1)
+        r2 = np.sum(d * d, axis=1)
+        cos = np.abs(d[:, 1]) / np.sqrt(r2)                          # floor normal and emitter normals are both +-y
+        return cos * cos / r2, cos, r2
+
+    est = np.zeros((len(P), 3)); true = np.zeros((len(P), 3))
+    s = 1.0 - eps / h
+    for k, x0 in enumerate(P):
+        c2 = np.array([x0[0], x0[2]])
+        for L, E in zip(lights, emit):
+            Ev = c2 + (E - c2) / s                                    # directions whose offset segment reaches the emitter
+            nodes, w = _poly_nodes(Ev, big)
+            g, _, _ = kernel(x0, nodes)
+            first = float(np.sum(g * w))
+            extra = 0.0
+            for cell, C, S, rule in cells:
+                piece = _clip_convex(Ev, cell)
+                if len(piece) < 3:
+                    continue
+                nodes, w = _poly_nodes(piece, rule)
+                g, cos, r2 = kernel(x0, nodes)
+                p_b = cos / math.pi
+                solid = r2 / cos / (2.0 * n_l)
+                extra += float(np.sum(g * ((0.5 * p_b + S * solid) / (0.5 * p_b + C * solid) - 1.0) * w))
+            le = np.asarray(L["emission"], float)
+            true[k] += alb / math.pi * le * first
+            est[k] += alb / math.pi * le * (first + extra)
+    return est, true
