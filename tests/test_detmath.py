@@ -35,6 +35,17 @@ def test_accuracy_against_libm(orc):
     assert ulp_diff(_vec(orc, 5, c), _libm(math.acos, c)).max() <= 1
     y, xx = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
     assert ulp_diff(_vec(orc, 6, y, xx), _libm(math.atan2, y, xx)).max() <= 1
+    # the one-division forms (round 2): around the switch points of acos (|x| = 0.5, 1) and of atan2 (|y/x| = tan(pi/8), 1),
+    # where atan2's quotient of two rounded sums can cost a second ulp
+    edge = np.concatenate([rng.uniform(0.49, 0.51, 4000), -rng.uniform(0.49, 0.51, 4000), 1 - np.exp(rng.uniform(-40, -1, 4000)),
+                           np.exp(rng.uniform(-40, -1, 4000)) - 1, np.exp(rng.uniform(-40, -1, 2000))])
+    assert ulp_diff(_vec(orc, 5, edge), _libm(math.acos, edge)).max() <= 1
+    xs = rng.uniform(-1, 1, 8000)
+    for ratio in (rng.uniform(0.41, 0.42, 8000), rng.uniform(0.99, 1.01, 8000)):
+        assert ulp_diff(_vec(orc, 6, ratio * xs, xs), _libm(math.atan2, ratio * xs, xs)).max() <= 2
+        assert ulp_diff(_vec(orc, 6, xs, ratio * xs), _libm(math.atan2, xs, ratio * xs)).max() <= 2
+    wy, wx = (np.exp(rng.uniform(-300, 300, 8000)) * rng.choice([-1, 1], 8000) for _ in range(2))
+    assert ulp_diff(_vec(orc, 6, wy, wx), _libm(math.atan2, wy, wx)).max() <= 1
     p = np.exp(rng.uniform(-30, 30, n))
     assert ulp_diff(_vec(orc, 10, p), _libm(math.log, p)).max() <= 1
     assert ulp_diff(_vec(orc, 8, p), _libm(math.log2, p)).max() <= 2
@@ -68,6 +79,14 @@ def test_special_values(orc):
     d = orc.detmath
     assert d(5, 1.0) == 0.0 and d(5, -1.0) == np.pi and np.isnan(d(5, 1.0000001))
     assert d(6, 0.0, -1.0) == np.pi and d(6, 0.0, 1.0) == 0.0 and d(6, 1.0, 0.0) == np.pi / 2 and d(6, -1.0, 0.0) == -np.pi / 2
+    import math
+    inf = math.inf
+    for y, x in [(0.0, 0.0), (-0.0, 0.0), (0.0, -0.0), (-0.0, -0.0), (1.0, 1.0), (-1.0, 1.0), (1.0, -1.0), (-1.0, -1.0), (inf, inf), (inf, -inf),
+                 (-inf, inf), (1.0, inf), (1.0, -inf), (-1.0, -inf), (inf, 1.0), (-inf, -1.0), (1e-310, 1.0), (1e-310, -1.0), (1.0, 1e-310), (-0.0, 1.0), (-0.0, -1.0)]:
+        got, want = d(6, y, x), math.atan2(y, x)
+        assert got == want and math.copysign(1.0, got) == math.copysign(1.0, want), (y, x, got, want)
+    assert np.isnan(d(6, np.nan, 1.0)) and np.isnan(d(6, 1.0, np.nan)) and np.isnan(d(5, np.nan)) and np.isnan(d(5, -1.0000001))
+    assert d(5, 0.5) == math.acos(0.5) and d(5, -0.5) == math.acos(-0.5) and d(5, 0.0) == math.pi / 2 and d(5, 1e-20) == math.pi / 2
     assert d(3, 0.0) == 0.0 and d(4, 0.0) == 1.0 and np.isnan(d(3, np.inf)) and np.isnan(d(4, np.nan))
     assert d(10, 1.0) == 0.0 and d(10, 0.0) == -np.inf and np.isnan(d(10, -1.0)) and d(10, np.inf) == np.inf
     assert d(11, 0.0) == 1.0 and d(11, 1000.0) == np.inf and d(11, -1000.0) == 0.0

@@ -168,160 +168,85 @@ PT_DM int dm_rem_pio2(double x, double& y0, double& y1) {
 }
 PT_DM void sincos(double x, double& s, double& c) {
     double y0, y1;
-    int n = dm_rem_pio2(x, y0, y1);
-    int32_t ix = dm_hi(x) & 0x7fffffff;
-    if (ix <= 0x3fe921fb) {
-        s = dm_ksin(x, 0.0);
-        c = dm_kcos(x, 0.0);
-        return;
-    }
-    double ks = dm_ksin(y0, y1), kc = dm_kcos(y0, y1);
-    switch (n & 3) {
-    case 0: s = ks; c = kc; break;
-    case 1: s = kc; c = -ks; break;
-    case 2: s = -ks; c = -kc; break;
-    default: s = -kc; c = ks; break;
-    }
+    const int n = dm_rem_pio2(x, y0, y1);   // |x| <= pi/4: n = 0, y0 = x, y1 = 0 — ONE copy of the kernels serves every lane of a wave
+    const double ks = dm_ksin(y0, y1), kc = dm_kcos(y0, y1);
+    const double a = (n & 1) ? kc : ks, b = (n & 1) ? ks : kc;   // quadrant: 0 (s, c)  1 (c, -s)  2 (-s, -c)  3 (-c, s)
+    s = (n & 2) ? -a : a;
+    c = ((n + 1) & 2) ? -b : b;
 }
 PT_DM double sin(double x) { double s, c; sincos(x, s, c); return s; }
 PT_DM double cos(double x) { double s, c; sincos(x, s, c); return c; }
 
 // ---- acos -----------------------------------------------------------------------------
+// fdlibm's e_acos.c rational approximation R(z) = p(z)/q(z) of (asin(s) - s)/s, z = s^2, with its three argument ranges
+// folded into ONE straight-line form (a wave of rays spans all three, and every branch a wave takes costs every lane):
+//   |x| <  0.5 : z = x^2,          acos = pi/2 - (x + x R)
+//   |x| >= 0.5 : z = (1 - |x|)/2,  s = sqrt(z),  acos = 2 asin(s) (x > 0)  or  pi - 2 asin(s) (x < 0),
+//                asin(s_true) - s = s R + e/(2s) with e = z - s^2 exactly (fma), the two quotients over one denominator:
+//                (2 z p + e q) / (2 s q)
+// so every lane evaluates the two polynomials once and divides once. <= 1 ulp from glibc on [-1, 1] (tests/test_detmath.py).
 PT_DM double acos(double x) {
     const double pi = 3.14159265358979311600e+00, pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
                  pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
                  pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
                  qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
                  qS4 = 7.70381505559019352791e-02;
-    int32_t hx = dm_hi(x);
-    int32_t ix = hx & 0x7fffffff;
-    if (ix >= 0x3ff00000) {   // |x| >= 1
-        if (((uint32_t)(ix - 0x3ff00000) | dm_lo(x)) == 0) {
-            if (hx > 0) return 0.0;
-            return pi + 2.0 * pio2_lo;
-        }
-        return dm_nan();
-    }
-    if (ix < 0x3fe00000) {   // |x| < 0.5
-        if (ix <= 0x3c600000) return pio2_hi + pio2_lo;
-        double z = x * x;
-        double p = z * dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, pS5, pS4), pS3), pS2), pS1), pS0);
-        double q = dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, qS4, qS3), qS2), qS1), 1.0);
-        double r = p / q;
-        return pio2_hi - (x - dm_fma(-x, r, pio2_lo));
-    }
-    if (hx < 0) {   // x < -0.5
-        double z = (1.0 + x) * 0.5;
-        double p = z * dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, pS5, pS4), pS3), pS2), pS1), pS0);
-        double q = dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, qS4, qS3), qS2), qS1), 1.0);
-        double s = dm_sqrt(z);
-        double r = p / q;
-        double w = dm_fma(r, s, -pio2_lo);
-        return pi - 2.0 * (s + w);
-    }
-    // x > 0.5
-    double z = (1.0 - x) * 0.5;
-    double s = dm_sqrt(z);
-    double df = dm_words(dm_hi(s), 0);
-    double c = dm_fma(-df, df, z) / (s + df);
-    double p = z * dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, pS5, pS4), pS3), pS2), pS1), pS0);
-    double q = dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, qS4, qS3), qS2), qS1), 1.0);
-    double r = p / q;
-    double w = dm_fma(r, s, c);
-    return 2.0 * (df + w);
+    const double ax = dm_abs(x);
+    if (!(ax <= 1.0)) return dm_nan();   // |x| > 1 or NaN
+    const bool big = ax >= 0.5;
+    const double z = big ? (1.0 - ax) * 0.5 : x * x;
+    const double p = z * dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, pS5, pS4), pS3), pS2), pS1), pS0);
+    const double q = dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, qS4, qS3), qS2), qS1), 1.0);
+    const double s = big ? dm_sqrt(z) : 0.0;
+    const double e = dm_fma(-s, s, z);
+    const double num = big ? dm_fma(2.0 * z, p, e * q) : p;
+    double den = big ? 2.0 * s * q : q;
+    if (den == 0.0) den = 1.0;           // x = +-1: s = 0 and num = 0
+    const double r = num / den;
+    if (!big) return pio2_hi - (x - dm_fma(-x, r, pio2_lo));
+    return x > 0.0 ? 2.0 * (s + r) : pi - 2.0 * (s + (r - pio2_lo));
 }
 
 // ---- atan / atan2 ---------------------------------------------------------------------
-PT_DM double atan(double x) {
-    const double hi0 = 4.63647609000806093515e-01, hi1 = 7.85398163397448278999e-01, hi2 = 9.82793723247329054082e-01,
-                 hi3 = 1.57079632679489655800e+00;
-    const double lo0 = 2.26987774529616870924e-17, lo1 = 3.06161699786838301793e-17, lo2 = 1.39033110312309984516e-17,
-                 lo3 = 6.12323399573676603587e-17;
+// atan2 in one straight-line form with ONE division (fdlibm's e_atan2.c + s_atan.c take a quotient y/x, then one of four
+// reductions — three with a second quotient — and a wave of directions takes them all). With a = min(|x|,|y|),
+// b = max(|x|,|y|) the angle of (b, a) is in [0, pi/4]; past tan(pi/8) it is taken relative to pi/4:
+//   atan(a/b) = pi/4 + atan((a - b)/(a + b)),
+// so t = num/den has |t| <= tan(pi/8) < 0.4375, the range of s_atan.c's odd polynomial aT[]. Then the octant is undone:
+// K + sigma r with a two-term K = 0, pi/2 or pi, then the sign of y. Signed zeros follow IEEE
+// (atan2(+-0, -0) = +-pi); NaN in, NaN out. <= 1 ulp from glibc, 2 ulp in narrow bands around |y/x| = tan(pi/8) (tests/test_detmath.py).
+PT_DM double atan2(double y, double x) {
+    const double pio4_hi = 7.85398163397448278999e-01, pio4_lo = 3.06161699786838301793e-17, pio2_hi = 1.57079632679489655800e+00,
+                 pio2_lo = 6.12323399573676603587e-17, pi_hi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16,
+                 tan_pio8 = 4.14213562373095034188e-01;
     const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
                  aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
                  aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
                  aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
-    int32_t hx = dm_hi(x);
-    int32_t ix = hx & 0x7fffffff;
-    int id;
-    if (ix >= 0x44100000) {   // |x| >= 2^66
-        if (ix > 0x7ff00000 || (ix == 0x7ff00000 && dm_lo(x) != 0)) return x + x;   // NaN
-        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+    if (x != x || y != y) return x + y;   // NaN
+    const double ax = dm_abs(x), ay = dm_abs(y);
+    const bool sw = ay > ax;
+    const double a = sw ? ax : ay, b = sw ? ay : ax;
+    bool far = a > tan_pio8 * b;
+    double num = far ? a - b : a;
+    double den = far ? b + a : b;
+    if (a == b) {                        // the diagonal (also inf/inf) and the origin (0/0): exact
+        far = b != 0.0;
+        num = 0.0;
+        den = 1.0;
     }
-    if (ix < 0x3fdc0000) {   // |x| < 0.4375
-        if (ix < 0x3e200000) return x;   // |x| < 2^-29
-        id = -1;
-    } else {
-        x = dm_abs(x);
-        if (ix < 0x3ff30000) {   // |x| < 1.1875
-            if (ix < 0x3fe60000) { id = 0; x = dm_fma(2.0, x, -1.0) / (2.0 + x); }
-            else { id = 1; x = (x - 1.0) / (x + 1.0); }
-        } else {
-            if (ix < 0x40038000) { id = 2; x = (x - 1.5) / dm_fma(1.5, x, 1.0); }
-            else { id = 3; x = -1.0 / x; }
-        }
-    }
-    double z = x * x;
-    double w = z * z;
-    double s1 = z * dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, aT10, aT8), aT6), aT4), aT2), aT0);
-    double s2 = w * dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, aT9, aT7), aT5), aT3), aT1);
-    if (id < 0) return dm_fma(-x, s1 + s2, x);
-    double ahi = id == 0 ? hi0 : id == 1 ? hi1 : id == 2 ? hi2 : hi3;
-    double alo = id == 0 ? lo0 : id == 1 ? lo1 : id == 2 ? lo2 : lo3;
-    z = ahi - (dm_fma(x, s1 + s2, -alo) - x);
-    return hx < 0 ? -z : z;
-}
-PT_DM double atan2(double y, double x) {
-    const double tiny = 1.0e-300, pi_o_4 = 7.8539816339744827900E-01, pi_o_2 = 1.5707963267948965580E+00,
-                 pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
-    int32_t hx = dm_hi(x), hy = dm_hi(y);
-    int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
-    uint32_t lx = dm_lo(x), ly = dm_lo(y);
-    if (((uint32_t)ix | ((lx | (0u - lx)) >> 31)) > 0x7ff00000u || ((uint32_t)iy | ((ly | (0u - ly)) >> 31)) > 0x7ff00000u) return x + y;   // NaN
-    if ((((uint32_t)hx - 0x3ff00000u) | lx) == 0) return atan(y);   // x == 1.0
-    int m = (int)(((uint32_t)hy >> 31) & 1u) | (int)(((uint32_t)hx >> 30) & 2u);   // 2*sign(x) + sign(y)
-    if (((uint32_t)iy | ly) == 0) {   // y == 0
-        switch (m) {
-        case 0:
-        case 1: return y;
-        case 2: return pi + tiny;
-        default: return -pi - tiny;
-        }
-    }
-    if (((uint32_t)ix | lx) == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;   // x == 0
-    if (ix == 0x7ff00000) {
-        if (iy == 0x7ff00000) {
-            switch (m) {
-            case 0: return pi_o_4 + tiny;
-            case 1: return -pi_o_4 - tiny;
-            case 2: return 3.0 * pi_o_4 + tiny;
-            default: return -3.0 * pi_o_4 - tiny;
-            }
-        }
-        switch (m) {
-        case 0: return 0.0;
-        case 1: return -0.0;
-        case 2: return pi + tiny;
-        default: return -pi - tiny;
-        }
-    }
-    if (iy == 0x7ff00000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
-    int32_t k = (iy - ix) >> 20;
-    double z;
-    if (k > 60) {
-        z = pi_o_2 + 0.5 * pi_lo;
-        m &= 1;
-    } else if (hx < 0 && k < -60) {
-        z = 0.0;
-    } else {
-        z = atan(dm_abs(y / x));
-    }
-    switch (m) {
-    case 0: return z;
-    case 1: return -z;
-    case 2: return pi - (z - pi_lo);
-    default: return (z - pi_lo) - pi;
-    }
+    const double t = num / den;
+    const double z = t * t;
+    const double w = z * z;
+    const double s1 = z * dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, aT10, aT8), aT6), aT4), aT2), aT0);
+    const double s2 = w * dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, aT9, aT7), aT5), aT3), aT1);
+    double r = far ? pio4_hi - (dm_fma(t, s1 + s2, -pio4_lo) - t) : dm_fma(-t, s1 + s2, t);
+    // octant: angle = K + sigma r with K = 0, pi/2, pi/2, pi and sigma = +, -, +, - for (x >= 0, |y| <= |x|), (x >= 0, |y| > |x|),
+    // (x < 0, |y| > |x|), (x < 0, |y| <= |x|): one two-term constant, one final rounding
+    const bool xneg = (int64_t)dm_bits(x) < 0;
+    const double k_hi = sw ? pio2_hi : xneg ? pi_hi : 0.0, k_lo = sw ? pio2_lo : xneg ? pi_lo : 0.0;
+    r = k_hi + ((sw != xneg ? -r : r) + k_lo);
+    return (int64_t)dm_bits(y) < 0 ? -r : r;
 }
 
 // ---- log / log2 -----------------------------------------------------------------------

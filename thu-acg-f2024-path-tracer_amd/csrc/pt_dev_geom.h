@@ -320,9 +320,14 @@ PT_DEV RayD generate_ray(const CamD& cam, uint32_t row, uint32_t col, Rng& rng) 
     bx = bx * cam.blur_strength;
     by = by * cam.blur_strength;
     V3 sample_location = ld3(cam.pixel00) + (ld3(cam.pixel_dv) * ((double)row + bx)) + (ld3(cam.pixel_du) * ((double)col + by));
-    double px, py;
-    random_offsets(rng, px, py);
-    V3 origin = ld3(cam.center) + (ld3(cam.dof_right) * px) + (ld3(cam.dof_up) * py);
+    V3 origin = ld3(cam.center);
+    if (cam.lens_zero) {
+        rng.draw += 2;   // the two lens draws are made all the same (camera.rs:160); their products with a zero radius add nothing
+    } else {
+        double px, py;
+        random_offsets(rng, px, py);
+        origin = origin + (ld3(cam.dof_right) * px) + (ld3(cam.dof_up) * py);
+    }
     double time = rng_f64(rng);
     return make_ray(origin, sample_location - origin, time);
 }

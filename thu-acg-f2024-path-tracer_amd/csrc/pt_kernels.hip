@@ -750,6 +750,15 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     if (live) prof_class = in.hw >> HIT_CLASS_SHIFT;
     prof_class = (uint32_t)__builtin_amdgcn_readfirstlane((int)prof_class);
 #endif
+    // Lanes that are certain to end here — the ray left the scene (class in K2's result word) or the slot is idle — are known
+    // before anything is computed: their work items are requested NOW, so that the returning atomic's round trip to the work
+    // counter (~3 k cycles, which only the SIMD's other wave could cover) runs under the environment lookup instead of in
+    // front of the regeneration. Phase C consumes the answer; paths that end on a surface ask there, as before.
+    unsigned long long early = 0ull, early_base = 0ull;
+    if (pool.dynamic) {
+        early = __ballot(alive && (was_idle || (in.hw >> HIT_CLASS_SHIFT) == CLASS_MISS));
+        if (early && lane == __ffsll((long long)early) - 1) early_base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(early));
+    }
     // ---- phase A: all global-memory reads of the bounce -------------------------------------------------------------
     bool is_hit = false;
     HitD hit{};
@@ -824,12 +833,18 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         // that still has items — without this, slots died while other shards still held work and the frame ended
         // on a long, thin tail.
         parked = parked && pool.defer_regen != 0u;
-        unsigned long long need = __ballot(alive && finished && !parked);
+        // first round: the early request's answer (its lanes are a subset of the finished ones); then whoever is still without
+        unsigned long long need = early ? early : __ballot(alive && finished && !parked);
+        bool have_base = early != 0ull;
         while (need) {
             const int leader = __ffsll((long long)need) - 1;
             const bool asking = (need >> lane) & 1ull;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(need));
+            unsigned long long base = early_base;
+            if (!have_base) {
+                base = 0;
+                if (lane == leader) base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(need));
+            }
+            have_base = false;
             base = __shfl(base, leader);
             if (asking) {
                 const unsigned long long w = shard_item(base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull)), shard);
@@ -838,14 +853,14 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
                     next_idle = !work_to_pixel(pool, w, next_pixel, next_sample, next_row, next_col);
                 }
             }
-            need = __ballot(asking && !more);
-            if (need) {
+            if (__ballot(asking && !more)) {
                 static_assert(WORK_SHARDS == 64, "one lane per shard");
                 const unsigned long long live_shards = __ballot(shard_item(cnt->work[lane].next, (uint32_t)lane) < pool.total_work);
                 if (live_shards == 0ull) break;                                       // the frame's sample budget is handed out
                 const unsigned long long above = live_shards & ~((2ull << shard) - 1ull);   // next live shard after this one, cyclically
                 shard = (uint32_t)(__ffsll((long long)(above ? above : live_shards)) - 1);
             }
+            need = __ballot(alive && finished && !parked && !more);
         }
     } else if (alive && finished) {
         pool.ax[s] += rad.x; pool.ay[s] += rad.y; pool.az[s] += rad.z;

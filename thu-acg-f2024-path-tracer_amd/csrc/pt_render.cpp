@@ -185,6 +185,14 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     dc.env_is_map = cam->env_is_map ? 1u : 0u;
     dc.env_tex = cam->env_tex;
     dc.n_lights = s->dev.view.n_lights;
+    {   // camera.rs:159-163 with radius 0: origin = center + 0 * px + 0 * py = center bit for bit (px, py are finite), unless a
+        // component of center is -0.0 (then -0 + +0 = +0): only then must the products be formed
+        bool zero = true;
+        for (int i = 0; i < 3; ++i)
+            zero = zero && dc.dof_right[i] == 0.0 && dc.dof_up[i] == 0.0 && !(dc.center[i] == 0.0 && std::signbit(dc.center[i]));
+        dc.lens_zero = zero ? 1u : 0u;
+        dc.pad_ = 0;
+    }
     if (dc.env_is_map) {
         if (cam->env_tex < 0 || (size_t)cam->env_tex >= s->tex.size() || s->tex[cam->env_tex].d.kind != TEX_IMAGE)
             return set_error("pt_render: env_tex must be an image texture of this scene");

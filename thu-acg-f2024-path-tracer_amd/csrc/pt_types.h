@@ -101,6 +101,8 @@ struct CamD {
     uint32_t width, height, max_depth, env_is_map;
     int32_t env_tex;
     uint32_t n_lights;
+    uint32_t lens_zero;      // defocus radius 0 (dof_right = dof_up = 0, no -0.0 in center): the lens point is `center` exactly
+    uint32_t pad_;
 };
 
 struct SceneD {
