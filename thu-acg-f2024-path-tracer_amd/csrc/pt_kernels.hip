@@ -196,7 +196,6 @@ PT_DEV void test_world_prim(const SceneD& sc, const RayD& r, double t_min, uint3
         if (h) consider(best, t, gid);
     }
 }
-struct Box6 { float lo[3], hi[3]; };   // SceneD::entry_box record
 
 PT_DEV Closest closest_hit(const SceneD& sc, const RayD& wray, double t_min, uint32_t* stk /* &stack[0][lane] */) {
     Closest best{D_INF, HIT_NONE};
@@ -315,42 +314,180 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
 
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best);
 
-// Closest hit with the top level walked FLAT (SceneD::tlas_flat: at most TLAS_FLAT_MAX world entries): the
-// wave loops over the entry list together — the entry index is wave-uniform, so boxes, entries and instance
-// transforms arrive by scalar loads, there is no top-level stack, and an entry no lane's ray enters costs one
-// f32 box test. Must be called by whole waves (`alive` = false for lanes without a ray).
-PT_DEV Closest closest_hit_flat(const SceneD& sc, bool alive, const RayD& r, double t_min, uint32_t* stk) {
-    Closest best{D_INF, HIT_NONE};
-    const float t_min_f = __double2float_rd(t_min);
-    float t_max_f = t_max_f32(best.t);
-    const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
-    for (uint32_t ei = 0; ei < sc.n_entries; ++ei) {
-        const Box6 bx = ldu(reinterpret_cast<const Box6*>(sc.entry_box) + ei);
-        float tn;
-        const bool hb = alive && slab_f32(bx.lo, bx.hi, f, t_min_f, t_max_f, tn);
-        if (__ballot(hb) == 0ull) continue;
-        const Entry e = ldu(&sc.entries[ei]);
-        if (hb) {
-            if (e.kind == ENTRY_MESH) {
-                blas_pass(sc, r, e, t_min, t_min_f, stk, TRAVERSAL_STACK, best);
-            } else {
-                const RayD lr = ray_to_local_chain<true>(sc, e.inst, r);
-                const uint32_t n = e.kind == ENTRY_CUBOID ? 6u : 1u;   // cuboid.rs: six quads, linear
-                for (uint32_t i = 0; i < n; ++i) test_world_prim<true>(sc, lr, t_min, e.first_prim + i, best);
-            }
-            t_max_f = t_max_f32(best.t);
+// ---- the FLAT top level (SceneD::tlas_flat: at most TLAS_FLAT_MAX world entries), walked by a whole wave ---------------------
+// The wave loops over the entry list together — the entry index is wave-uniform, so boxes and entries arrive by scalar loads
+// and there is no top-level stack. Round 2 measured what that loop cost when every entry whose box ANY lane entered was
+// tested on the spot by the whole wave: 46 % of k_extend2's time on scene 6 (ten entries: each 64-ray chunk ran five sphere
+// tests, one quad test and a cuboid's six, with a handful of lanes active in each). Now the box pass only RECORDS
+// (ray, primitive) pairs — ray = lane of the chunk, primitive = global id, one pair per cuboid face — in a small per-wave ring
+// in LDS, and whenever 64 pairs are waiting the wave tests them in ONE dense pass: lane i takes pair i, fetches that ray from
+// its owner lane (ds_bpermute), transforms it into the primitive's frame and runs the primitive's exact f64 test. Results
+// meet in LDS: minimum t per ray (64-bit LDS atomic min on the bits of the positive double), ties -> larger id (atomic max) —
+// the same order-independent rule as consider(), so the hit is bit-identical. Mesh entries come second, their boxes trimmed
+// by the non-mesh result.
+#ifndef PT_PAIR_DENSE_MIN
+#define PT_PAIR_DENSE_MIN 16        // lanes of a chunk in one entry's box from which the entry is tested on the spot (break-even of the two forms)
+#endif
+#ifndef PT_PAIR_PASS_ATTR
+#define PT_PAIR_PASS_ATTR PT_DEV
+#endif
+#ifndef PT_FLAT_DIRECT
+#define PT_FLAT_DIRECT 1            // 0: on-the-spot tests look the primitive up in prims[] (A/B)
+#endif
+#ifndef PT_PAIR_SINGLE
+#define PT_PAIR_SINGLE 1            // 0: only cuboids (six faces behind one transform) go through the pair passes
+#endif
+constexpr int PAIR_CAP = 128;       // ring of waiting pairs per wave (a pass runs as soon as 64 wait, an append adds <= 64)
+// pair word = id << 6 | lane: the host (pt_scene.cpp) only sets tlas_flat when the ids of spheres / quads / cuboid faces are below 2^26
+struct PairLds {                    // per wave
+    unsigned long long* bt;         // [64] bits of the closest t so far of every ray of the chunk (+inf: none)
+    uint32_t* bid;                  // [64] its primitive id
+    uint32_t* pairs;                // [PAIR_CAP]
+};
+// LDS operations of one wave execute in issue order; this keeps the compiler from moving them across the steps of the protocol
+PT_DEV void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+PT_PAIR_PASS_ATTR void pair_pass(const SceneD& sc, const RayD& r, double t_min, int lane, const PairLds& L, uint32_t head, uint32_t n) {
+    wave_lds_order();
+    const bool mine = (uint32_t)lane < n;
+    const uint32_t code = ((volatile uint32_t*)L.pairs)[(head + (uint32_t)lane) % PAIR_CAP];
+    const int src = mine ? (int)(code & 63u) : lane;
+    const uint32_t gid = code >> 6;
+    const RayD pr_ray{V3{__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src)}, V3{__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src)},
+                      __shfl(r.time, src)};
+    bool hit = false;
+    double t = 0.0;
+    if (mine) {
+        const PrimRef pr = sc.prims[gid];
+        const RayD lr = ray_to_local_chain(sc, pr.inst, pr_ray);
+        if ((pr.kind & 0xFFu) == PRIM_SPHERE) {
+            V3 c;
+            hit = hit_sphere(sc.spheres[pr.index], lr, t_min, t, c);
+        } else {
+            double a, b;
+            hit = hit_quad(sc.quads[pr.index], lr, t_min, t, a, b);
         }
     }
+    // t > t_min > 0: the bits of t order like t. Every winner of this pass holds the pass's minimum, so all of them see the same
+    // `before` and agree on whether the ray's closest t went down (older ids are void) or stayed (ids compete).
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+    volatile unsigned long long* bt = L.bt;
+    volatile uint32_t* bid = L.bid;
+    unsigned long long before = 0ull;
+    if (hit) before = bt[src];
+    hit = hit && tb <= before;
+    wave_lds_order();
+    if (hit) atomicMin(&L.bt[src], tb);
+    wave_lds_order();
+    const bool win = hit && bt[src] == tb;
+    if (win && tb < before) bid[src] = 0u;
+    wave_lds_order();
+    if (win) atomicMax(&L.bid[src], gid);
+    wave_lds_order();
+}
+// Must be called by whole waves (`alive` = false for lanes without a ray). on_mesh(ei, entry, best): a lane's ray entered the
+// box of mesh entry `ei` (wave-uniform index).
+// PAIRS: cuboids few rays of the chunk enter go through the pair passes (L must be valid); false: everything on the spot.
+template <bool PAIRS, class OnMesh>
+PT_DEV Closest flat_top_level(const SceneD& sc, bool alive, const RayD& r, const RayF& f, double t_min, float t_min_f, int lane, const PairLds& L,
+                              OnMesh&& on_mesh) {
+    if constexpr (PAIRS) {
+        ((volatile unsigned long long*)L.bt)[lane] = (unsigned long long)__double_as_longlong(D_INF);
+        ((volatile uint32_t*)L.bid)[lane] = HIT_NONE;
+    }
+    uint32_t head = 0, tail = 0;                                     // wave-uniform
+    Closest best{D_INF, HIT_NONE};                                   // hits of the entries tested on the spot
+    float t_max_f = t_max_f32(best.t);
+    bool pairs_open = PAIRS;                                         // wave-uniform: pair results not yet merged into `best`
+    auto close_pairs = [&]() {
+        if (tail != head) pair_pass(sc, r, t_min, lane, L, head, tail - head);
+        if (tail != 0u) {                                            // some pass ran: its results join the on-the-spot ones (same rule)
+            wave_lds_order();
+            const double lt = __longlong_as_double((long long)((volatile unsigned long long*)L.bt)[lane]);
+            if (lt < D_INF) consider(best, lt, ((volatile uint32_t*)L.bid)[lane]);
+            t_max_f = t_max_f32(best.t);
+        }
+        pairs_open = false;
+    };
+    for (uint32_t k = 0; k < sc.n_entries; ++k) {                    // SceneD::entry_box: non-mesh entries first
+        const EntryBox bx = ldu(&sc.entry_box[k]);
+        if (PAIRS && pairs_open && bx.kind == ENTRY_MESH) close_pairs();
+        float tn;
+        const bool hb = alive && slab_f32(bx.lo, bx.hi, f, t_min_f, t_max_f, tn);
+        const unsigned long long m = __ballot(hb);
+        if (m == 0ull) continue;
+        if (bx.kind == ENTRY_MESH) {
+            if (hb) {
+                const Entry e{bx.kind, bx.first_prim, bx.inst, bx.blas_root, bx.extent, bx.n_prims, {0u, 0u}};
+                on_mesh(bx.entry, e, best);
+                t_max_f = t_max_f32(best.t);
+            }
+            continue;
+        }
+        const uint32_t n_faces = bx.kind == ENTRY_CUBOID ? 6u : 1u;  // cuboid.rs: six quads, linear
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (!PAIRS || (!PT_PAIR_SINGLE && n_faces == 1u) || cnt >= (uint32_t)PT_PAIR_DENSE_MIN) {
+            // a box many rays of the chunk enter: the test on the spot, with the primitive's record in scalar registers, is
+            // cheaper than that many pairs — and its hits trim the boxes that follow
+            if (hb) {
+                const RayD lr = ray_to_local_chain<true>(sc, bx.inst, r);
+                if (PT_FLAT_DIRECT && bx.prim_kind == PRIM_SPHERE) {
+                    const SphereD sp = ldu(&sc.spheres[bx.prim_index]);
+                    double t;
+                    V3 c;
+                    if (hit_sphere(sp, lr, t_min, t, c)) consider(best, t, bx.first_prim);
+                } else if (PT_FLAT_DIRECT && bx.prim_kind == PRIM_QUAD) {
+                    for (uint32_t fi = 0; fi < n_faces; ++fi) {
+                        const QuadD qd = ldu(&sc.quads[bx.prim_index + fi]);
+                        double t, a, b;
+                        if (hit_quad(qd, lr, t_min, t, a, b)) consider(best, t, bx.first_prim + fi);
+                    }
+                } else {
+                    for (uint32_t fi = 0; fi < n_faces; ++fi) test_world_prim<true>(sc, lr, t_min, bx.first_prim + fi, best);
+                }
+                t_max_f = t_max_f32(best.t);
+            }
+            continue;
+        }
+        if constexpr (PAIRS) {
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            for (uint32_t fi = 0; fi < n_faces; ++fi) {
+                if (hb) ((volatile uint32_t*)L.pairs)[(tail + rank) % PAIR_CAP] = ((bx.first_prim + fi) << 6) | (uint32_t)lane;
+                tail += cnt;
+                if (tail - head >= 64u) {
+                    pair_pass(sc, r, t_min, lane, L, head, 64u);
+                    head += 64u;
+                }
+            }
+        }
+    }
+    if (PAIRS && pairs_open) close_pairs();
     return best;
+}
+template <bool PAIRS>
+PT_DEV Closest closest_hit_flat(const SceneD& sc, bool alive, const RayD& r, double t_min, uint32_t* stk, int lane, const PairLds& L) {
+    const float t_min_f = __double2float_rd(t_min);
+    const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
+    return flat_top_level<PAIRS>(sc, alive, r, f, t_min, t_min_f, lane, L,
+                                [&](uint32_t, const Entry& e, Closest& best) { blas_pass(sc, r, e, t_min, t_min_f, stk, TRAVERSAL_STACK, best); });
 }
 
 // K2, batch form: a fixed grid walks the pool with a grid-stride loop; each lane traverses one ray
 // at a time, a wave moves on when its slowest lane is done. Lowest overhead; SIMD utilisation
 // suffers when traversal lengths inside a wave differ a lot (sky ray next to a mesh ray). Used for
 // scenes without meshes (and as the fallback for BVHs deeper than k_extend2's LDS stack).
-template <bool FLAT>   // FLAT: SceneD::tlas_flat (two instantiations so that each keeps its own register budget)
-__global__ __launch_bounds__(BLOCK, PT_EXTEND_BATCH_BLOCKS) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
+// FLAT: SceneD::tlas_flat. PAIRS (FLAT only): SceneD::flat_pairs — the scene has cuboids, whose six faces behind one transform
+// are what the pair passes of flat_top_level pay for (scene 3: K2 -19 %, scene 7: -11 %); that instantiation runs three blocks
+// per CU (its extra state spills at 128 registers and costs more than the fourth block brings), the others four.
+template <bool FLAT, bool PAIRS>
+__global__ __launch_bounds__(BLOCK, PAIRS ? 3 : PT_EXTEND_BATCH_BLOCKS) void k_extend(SceneD sc, PoolD pool, CountersD* cnt) {
     __shared__ uint32_t stack[TRAVERSAL_STACK * BLOCK];
+    __shared__ unsigned long long s_pair_t[PAIRS ? BLOCK : 1];
+    __shared__ uint32_t s_pair_id[PAIRS ? BLOCK : 1], s_pairs[PAIRS ? (BLOCK / 64) * PAIR_CAP : 1];
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const PairLds pl{&s_pair_t[PAIRS ? wave * 64 : 0], &s_pair_id[PAIRS ? wave * 64 : 0], &s_pairs[PAIRS ? wave * PAIR_CAP : 0]};
     unsigned long long nseg = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
     // n_alloc is a multiple of BLOCK: whole waves run every chunk (closest_hit_flat ballots)
@@ -360,7 +497,7 @@ __global__ __launch_bounds__(BLOCK, PT_EXTEND_BATCH_BLOCKS) void k_extend(SceneD
         RayD r{};
         if (alive) r = load_ray(pool, s);
         Closest c{D_INF, HIT_NONE};
-        if (FLAT) c = closest_hit_flat(sc, alive, r, 1e-3, &stack[threadIdx.x]);   // camera.rs:171,179
+        if (FLAT) c = closest_hit_flat<PAIRS>(sc, alive, r, 1e-3, &stack[threadIdx.x], lane, pl);   // camera.rs:171,179
         else if (alive) c = closest_hit(sc, r, 1e-3, &stack[threadIdx.x]);
         stnt(&pool.hit_prim[s], hit_word(sc, alive ? c.id : dead_or_idle(state)));
         if (alive) ++nseg;
@@ -391,6 +528,28 @@ __global__ __launch_bounds__(BLOCK, PT_EXTEND_BATCH_BLOCKS) void k_extend(SceneD
 // fourth would cap it at 128 registers and the spills cost more than the extra waves bring (measured).
 // Tried and dropped: the two phases as two kernels with a global candidate list; every
 // wave on its own 256-slot window without block barriers; warming the next window's ray lines.
+#ifdef PT_STAMPS
+// Diagnostic build: where a k_shade wave spends its cycles (s_memtime ticks; MI355X_MICROARCH.md "In-kernel stamps"). The stamp
+// after the record loads forces vmcnt(0) so that the first segment is the pure fetch wait. Never part of the product build.
+PT_DEV unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__shared__ unsigned long long g_prof[N_CLASSES + 1][8];
+#define PT_STAMP(i) const unsigned long long t_##i = stamp()
+#define PT_STAMP_VAR(i) unsigned long long t_##i = 0
+#define PT_STAMP_SET(i) t_##i = stamp()
+#define PT_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PT_STAMP(i)
+#define PT_STAMP_VAR(i)
+#define PT_STAMP_SET(i)
+#define PT_DRAIN()
+#endif
+
 constexpr int EXT_WINDOW = 2048;   // slots per block window
 constexpr uint32_t REFILL_MIN = 16;   // idle lanes that trigger a refill of the wave in phase B
 constexpr int EXT_CAND = 768;      // candidate list of a window (LDS); a fuller window walks the rest in phase A
@@ -437,11 +596,15 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
     unsigned long long nseg = 0;
     const uint32_t n_windows = pool.n_alloc / EXT_WINDOW;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
+#ifdef PT_STAMPS
+    if (threadIdx.x < 8) g_prof[CLASS_DEAD][threadIdx.x] = 0ull;
+#endif
     for (;;) {
         if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_extend, 1ull); s_nrays = 0; s_next = 0; }
         __syncthreads();
         if (s_win >= n_windows) break;
         const uint32_t wbase = s_win * EXT_WINDOW;
+        PT_STAMP(e0);
         // ---- phase A: top level only ---------------------------------------------------------------
         // the ray of the NEXT chunk is requested before this chunk's traversal starts: with three waves per
         // SIMD nothing else hides the 2-3 us an HBM fetch takes
@@ -484,17 +647,13 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 }
             };
             if (sc.tlas_flat) {
-                // Small top level: the wave walks the ENTRY LIST together instead of each lane walking the tree.
-                // The entry index is wave-uniform, so boxes, entries and instance transforms arrive by scalar
-                // loads, there is no stack, and an entry no lane's ray enters costs one box test.
-                for (uint32_t ei = 0; ei < sc.n_entries; ++ei) {
-                    const Box6 bx = ldu(reinterpret_cast<const Box6*>(sc.entry_box) + ei);
-                    float tn;
-                    const bool hb = alive && slab_f32(bx.lo, bx.hi, f, t_min_f, t_max_f, tn);
-                    if (__ballot(hb) == 0ull) continue;
-                    const Entry e = ldu(&sc.entries[ei]);
-                    if (hb) visit_entry(std::true_type{}, ei, e, 0);
-                }
+                // Small top level: the wave walks the ENTRY LIST together instead of each lane walking the tree
+                // (flat_top_level; the pair passes are left to the batch kernel: measured slower here, scene 6).
+                best = flat_top_level<false>(sc, alive, r, f, t_min, t_min_f, lane, PairLds{}, [&](uint32_t ei, const Entry& e, Closest& b) {
+                    best = b;                                       // visit_entry works on this frame's `best`
+                    visit_entry(std::true_type{}, ei, e, 0);
+                    b = best;
+                });
             } else if (alive) {
                 int sp = 0;
                 uint32_t cur = sc.tlas_root;
@@ -536,7 +695,9 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
             }
             s_best_id[sl] = alive ? best.id : dead_or_idle(state);
         }
+        PT_STAMP(e1);
         __syncthreads();
+        PT_STAMP(e2);
         // ---- phase B: mesh traversals, 64 rays per pull ------------------------------------------------
         const uint32_t n_rays = s_nrays < (uint32_t)EXT_CAND ? s_nrays : (uint32_t)EXT_CAND;
         {
@@ -612,7 +773,19 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 }
             }
         }
+        PT_STAMP(e3);
         __syncthreads();
+        PT_STAMP(e4);
+#ifdef PT_STAMPS
+        if (lane == 0) {   // K2's row of the profile: CLASS_DEAD (k_shade never runs a group of that class)
+            atomicAdd(&g_prof[CLASS_DEAD][0], 1ull);
+            atomicAdd(&g_prof[CLASS_DEAD][1], t_e1 - t_e0);   // phase A
+            atomicAdd(&g_prof[CLASS_DEAD][2], t_e2 - t_e1);   // barrier
+            atomicAdd(&g_prof[CLASS_DEAD][3], t_e3 - t_e2);   // phase B
+            atomicAdd(&g_prof[CLASS_DEAD][4], t_e4 - t_e3);   // barrier
+            atomicAdd(&g_prof[CLASS_DEAD][5], (unsigned long long)n_rays);
+        }
+#endif
         {   // the window's result: one coalesced 4-byte store per slot; the eight PrimRef gathers (material class) go out together
             uint32_t word[EXT_WINDOW / BLOCK];
 #pragma unroll
@@ -623,6 +796,10 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         __syncthreads();   // LDS lists are reused by the next window
     }
     if (nseg) atomicAdd(&cnt->segments, nseg);
+#ifdef PT_STAMPS
+    __syncthreads();
+    if (threadIdx.x < 8 && g_prof[CLASS_DEAD][threadIdx.x]) atomicAdd(&cnt->prof[CLASS_DEAD][threadIdx.x], g_prof[CLASS_DEAD][threadIdx.x]);
+#endif
 }
 
 // K3: the body of camera.rs:177-226 for the path in slot `s`, executed by all 64 lanes of a wave
@@ -640,23 +817,7 @@ PT_DEV void add_radiance(const PoolD& pool, uint32_t pixel, V3& rad, V3 c) {
     }
 }
 
-#ifdef PT_STAMPS
-// Diagnostic build: where a k_shade wave spends its cycles (s_memtime ticks; MI355X_MICROARCH.md "In-kernel stamps"). The stamp
-// after the record loads forces vmcnt(0) so that the first segment is the pure fetch wait. Never part of the product build.
-PT_DEV unsigned long long stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-__shared__ unsigned long long g_prof[N_CLASSES + 1][8];
-#define PT_STAMP(i) const unsigned long long t_##i = stamp()
-#define PT_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define PT_STAMP(i)
-#define PT_DRAIN()
-#endif
+
 
 // ---- path records of one slot as k_shade consumes them -------------------------------------------------------------
 struct SlotIn {
@@ -764,6 +925,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     HitD hit{};
     const MatD* mp = nullptr;
     TexVals tv{};
+    PT_STAMP_VAR(a1);
     if (live) {
         if (!pool.dynamic) {
             pixel = s % pool.n_pixels;
@@ -771,7 +933,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         }
         rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, in.draw};
         const uint32_t gid = in.hw & HIT_ID_MASK;
-        if ((in.hw >> HIT_CLASS_SHIFT) == CLASS_MISS || !reconstruct_hit(sc, ray, gid, 1e-3, hit)) {
+        const bool surface = (in.hw >> HIT_CLASS_SHIFT) != CLASS_MISS && reconstruct_hit(sc, ray, gid, 1e-3, hit);
+        PT_STAMP_SET(a1);
+        if (!surface) {
             add_radiance(pool, pixel, rad, thr * sample_environment(sc, cam, ray.d));   // camera.rs:180-183
             finished = true;
         } else {
@@ -784,6 +948,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             add_radiance(pool, pixel, rad, thr * emission);
         }
     }
+    PT_STAMP(a2);
     const bool any_hit = __ballot(is_hit) != 0ull;
     bool fetched = false;                                              // wave-uniform
     if (any_hit && sc.n_lights == 0u) { prefetch(); fetched = true; }  // P1
@@ -808,6 +973,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             else have_dir = true;
         }
     }
+    PT_STAMP(b1);
     if (any_hit && !fetched) { prefetch(); fetched = true; }           // P1b
     // ---- phase B2: pdf, eval, throughput, next ray (arithmetic only; lights.pdf reads through the scalar cache) -----------------
     if (have_dir) {
@@ -902,6 +1068,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     PT_STAMP(4);
     if (lane == 0) {   // block-local sums in LDS (global atomics here would themselves be what the next group waits for)
         atomicAdd(&g_prof[prof_class][0], 1ull);
+        atomicAdd(&g_prof[prof_class][1], (t_a1 ? t_a1 : t_a2) - t_1);   // records unpacked, hit reconstructed
+        atomicAdd(&g_prof[prof_class][6], t_a2 - (t_a1 ? t_a1 : t_a2));  // environment / textures
+        atomicAdd(&g_prof[prof_class][7], t_b1 - t_a2);                  // roulette + direction
         atomicAdd(&g_prof[prof_class][2], t_2 - t_1);
         atomicAdd(&g_prof[prof_class][3], t_3 - t_2);
         atomicAdd(&g_prof[prof_class][4], t_4 - t_3);
@@ -1176,9 +1345,13 @@ static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min 
     default: return k_extend2<24, 3>;   // 24 stack entries: 43.5 KB of LDS per block, three blocks per CU
     }
 }
+typedef void (*extend_fn)(SceneD, PoolD, CountersD*);
+static extend_fn pick_extend_batch(uint32_t flat, uint32_t pairs) {
+    return !flat ? k_extend<false, false> : pairs ? k_extend<true, true> : k_extend<true, false>;
+}
 void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int code, hipStream_t st) {   // code: pt_render.cpp extend_code
     if (code <= -100) hipLaunchKernelGGL(pick_extend2(-code), grid_for((pool.n_alloc / EXT_WINDOW) * BLOCK, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
-    else hipLaunchKernelGGL(sc.tlas_flat ? k_extend<true> : k_extend<false>, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    else hipLaunchKernelGGL(pick_extend_batch(sc.tlas_flat, sc.flat_pairs), grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
 }
 typedef void (*shade_fn)(SceneD, CamD, PoolD, CountersD*, uint64_t);
 static shade_fn pick_shade(int variant) {   // variant = sort*10 + min waves per SIMD
@@ -1209,7 +1382,7 @@ void launch_math_probe(int which, const double* in, uint32_t n, double* out, hip
 }
 int kernel_occupancy_blocks(int which, int variant) {
     int nb = 0;
-    const void* f = which == 0 ? (variant <= -100 ? (const void*)pick_extend2(-variant) : variant == -2 ? (const void*)k_extend<true> : (const void*)k_extend<false>) : (const void*)pick_shade(variant);
+    const void* f = which == 0 ? (variant <= -100 ? (const void*)pick_extend2(-variant) : (const void*)pick_extend_batch(variant <= -2, variant == -3)) : (const void*)pick_shade(variant);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

@@ -316,7 +316,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (!strcmp(e, "batch")) extend_code = -1;
         else if (!strcmp(e, "twophase") && extend2_code() != 0) extend_code = -extend2_code();
     }
-    const int blocks_extend = kernel_occupancy_blocks(0, extend_code == -1 && s->dev.view.tlas_flat ? -2 : extend_code), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
+    const int blocks_extend = kernel_occupancy_blocks(0, extend_code == -1 && s->dev.view.tlas_flat ? (s->dev.view.flat_pairs ? -3 : -2) : extend_code), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;
@@ -385,8 +385,16 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         static const char* names[N_CLASSES + 1] = {"miss", "diffuse", "metal", "glass", "principled", "light", "sheen", "clearcoat", "mix", "idle", "dead", "WINDOW"};
         for (uint32_t c = 0; c <= N_CLASSES; ++c) {
             const unsigned long long* p = s->h_counters->prof[c];
-            if (p[0]) fprintf(stderr, "[pt prof] %-10s n %10llu  load %8.0f  body %8.0f  dequeue %8.0f  regen+store %8.0f  whole %8.0f (cycles per wave-group; WINDOW row: n windows, sort / shade / barrier wait per window, then groups and summed record-wait cycles)\n", names[c],
-                              p[0], (double)p[1] / p[0], (double)p[2] / p[0], (double)p[3] / p[0], (double)p[4] / p[0], (double)p[5] / p[0]);
+            if (p[0] && c == CLASS_DEAD)
+                fprintf(stderr, "[pt prof] K2 window  n %10llu  phase A %8.0f  barrier %8.0f  phase B %8.0f  barrier %8.0f  candidates %6.1f (cycles per window and wave)\n", p[0],
+                        (double)p[1] / p[0], (double)p[2] / p[0], (double)p[3] / p[0], (double)p[4] / p[0], (double)p[5] / p[0]);
+            else if (p[0] && c < N_CLASSES)
+                fprintf(stderr, "[pt prof] %-10s n %10llu  body %8.0f = hit %7.0f + env/tex %7.0f + direction %7.0f + pdf/eval/ray %7.0f  dequeue %8.0f  regen+store %8.0f  whole %8.0f (cycles per wave-group)\n",
+                        names[c], p[0], (double)p[2] / p[0], (double)p[1] / p[0], (double)p[6] / p[0], (double)p[7] / p[0], (double)(p[2] - p[1] - p[6] - p[7]) / p[0],
+                        (double)p[3] / p[0], (double)p[4] / p[0], (double)p[5] / p[0]);
+            else if (p[0])
+                fprintf(stderr, "[pt prof] WINDOW     n %10llu  sort %8.0f  shade %8.0f  barrier wait %8.0f  groups %8.0f  record wait %8.0f (cycles per window and wave)\n", p[0],
+                        (double)p[1] / p[0], (double)p[2] / p[0], (double)p[3] / p[0], (double)p[4] / p[0], (double)p[5] / p[0]);
         }
     }
     if (stats) {

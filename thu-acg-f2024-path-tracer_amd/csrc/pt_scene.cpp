@@ -685,8 +685,35 @@ int pt::scene_build(pt_scene* s) {
             t.flat = solid ? 1u : 0u;
             for (int c = 0; c < 3; ++c) { t.c1[c] = solid ? a.v[c] : 0.0; t.c2[c] = solid ? b.v[c] : 0.0; }
         }
-    std::vector<float> entry_box(6 * entries.size());   // tlas_items[i] is entry i (built in entry order, before the builder permutes them)
-    for (size_t i = 0; i < entry_boxes.size(); ++i) Builder::store_box(entry_boxes[i], &entry_box[6 * i], &entry_box[6 * i + 3]);
+    std::vector<EntryBox> entry_box;   // tlas_items[i] is entry i (built in entry order, before the builder permutes them)
+    for (int pass = 0; pass < 2; ++pass)   // spheres / quads / cuboids first: their hits trim the mesh boxes
+        for (size_t i = 0; i < entry_boxes.size(); ++i) {
+            if ((entries[i].kind == ENTRY_MESH) != (pass == 1)) continue;
+            EntryBox eb{};
+            const Entry& e = entries[i];
+            Builder::store_box(entry_boxes[i], eb.lo, eb.hi);
+            eb.entry = (uint32_t)i;
+            eb.kind = e.kind;
+            eb.first_prim = e.first_prim;
+            eb.inst = e.inst;
+            eb.blas_root = e.blas_root;
+            eb.extent = e.extent;
+            eb.n_prims = e.n_prims;
+            eb.prim_kind = ENTRYBOX_VIA_PRIMREF;
+            if (e.kind != ENTRY_MESH) {   // one kind, consecutive records: the walk addresses them without prims[]
+                const PrimRef& p0 = prims[e.first_prim];
+                bool direct = true;
+                for (uint32_t k = 0; k < e.n_prims; ++k) {
+                    const PrimRef& pk = prims[e.first_prim + k];
+                    direct = direct && (pk.kind & 0xFFu) == (p0.kind & 0xFFu) && pk.index == p0.index + k && pk.inst == e.inst;
+                }
+                if (direct) {
+                    eb.prim_kind = p0.kind & 0xFFu;
+                    eb.prim_index = p0.index;
+                }
+            }
+            entry_box.push_back(eb);
+        }
     SceneD v{};
     DeviceBuffers& dev = s->dev;
     bool ok = upload(dev, nodes, v.nodes) && upload(dev, entries, v.entries) && upload(dev, prims, v.prims) &&
@@ -705,7 +732,11 @@ int pt::scene_build(pt_scene* s) {
     v.n_lights = (uint32_t)lights.size();
     uint32_t flat_max = TLAS_FLAT_MAX;
     if (const char* ev = exp_env("PT_FLAT_MAX")) flat_max = (uint32_t)atoi(ev);
-    v.tlas_flat = entries.size() <= flat_max && !exp_env("PT_NO_FLAT_TLAS") ? 1u : 0u;
+    bool pair_ids_fit = true;   // the flat walk packs (primitive id, lane) into one word: ids of spheres / quads / cuboid faces below 2^26
+    for (const Entry& e : entries) pair_ids_fit = pair_ids_fit && (e.kind == ENTRY_MESH || (uint64_t)e.first_prim + e.n_prims <= (1ull << 26));
+    v.tlas_flat = entries.size() <= flat_max && pair_ids_fit && !exp_env("PT_NO_FLAT_TLAS") ? 1u : 0u;
+    v.flat_pairs = 0;
+    for (const Entry& e : entries) v.flat_pairs |= (v.tlas_flat && e.kind == ENTRY_CUBOID && !exp_env("PT_NO_FLAT_PAIRS")) ? 1u : 0u;
     s->stack_need_extend2 = v.tlas_flat ? (uint32_t)(max_blas_depth + 1) : s->stack_need;
     dev.view = v;
     s->n_prims = v.n_prims;

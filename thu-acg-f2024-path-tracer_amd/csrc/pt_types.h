@@ -53,6 +53,24 @@ struct Entry {           // one per world-level object (lights list first, then 
     uint32_t n_prims;    // 1 (sphere, quad), 6 (cuboid) or the triangle count (mesh)
     uint32_t pad[2];
 };
+// Flat top-level walk (SceneD::tlas_flat): everything a step of the walk needs in ONE 64-byte record, i.e. one scalar load — the
+// entry's world-space box (padded and rounded outward like the node boxes), a copy of its Entry, and for spheres / quads /
+// cuboids the record index of the (first) primitive, so that neither Entry nor PrimRef has to be fetched first: with a
+// handful of waves per SIMD every dependent scalar load is ~200 exposed cycles, and the walk made three per entry.
+struct EntryBox {
+    float lo[3], hi[3];
+    uint32_t entry;      // index into SceneD::entries
+    uint32_t kind;       // EntryKind                                    -- Entry's fields from here
+    uint32_t first_prim;
+    int32_t inst;
+    uint32_t blas_root;
+    float extent;
+    uint32_t n_prims;
+    uint32_t prim_kind;  // PRIM_SPHERE / PRIM_QUAD of the entry's primitives, or ENTRYBOX_VIA_PRIMREF: look them up in prims[]
+    uint32_t prim_index; // spheres[] / quads[] index of primitive first_prim (the faces of a cuboid follow consecutively)
+    uint32_t pad;
+};
+constexpr uint32_t ENTRYBOX_VIA_PRIMREF = 0xFFFFFFFFu;
 struct SphereD { double r, p1[3], p2[3]; };
 struct QuadD { double q[3], u[3], v[3], w[3], n[3], d; };
 struct TriD { double v0[3], v1[3], v2[3]; };
@@ -122,8 +140,9 @@ struct SceneD {
     uint32_t tlas_root;          // child reference of the top-level root
     float tlas_extent;           // max |coordinate| of the top-level BVH boxes
     uint32_t n_entries, n_prims, n_lights;
-    const float* entry_box;      // lo[3], hi[3] per entry: its world-space box, padded and rounded outward like the node boxes
+    const EntryBox* entry_box;   // the flat top level's walk list: one record per entry, NON-MESH entries first (each group in entry order)
     uint32_t tlas_flat;          // n_entries <= TLAS_FLAT_MAX: K2 walks the entry list instead of the top-level tree
+    uint32_t flat_pairs;         // tlas_flat and the scene has cuboids: the batch K2 runs its (ray, primitive) pair passes
 };
 constexpr uint32_t TLAS_FLAT_MAX = 24;   // round 1 (vector loads): 8-10 entries -26 % / -7 % K2 time, 17 entries (scene 5) +20 % -> limit 12;
                                           // round 2 (scalar loads, ldu): 17 entries -20 % -> limit raised
