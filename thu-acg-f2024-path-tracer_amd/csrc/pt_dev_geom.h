@@ -328,7 +328,9 @@ PT_DEV RayD generate_ray(const CamD& cam, uint32_t row, uint32_t col, Rng& rng) 
         random_offsets(rng, px, py);
         origin = origin + (ld3(cam.dof_right) * px) + (ld3(cam.dof_up) * py);
     }
-    double time = rng_f64(rng);
+    double time = 0.0;
+    if (cam.motionless) ++rng.draw;   // drawn all the same (camera.rs:165); no result depends on it (CamD::motionless), so its Philox block is not computed
+    else time = rng_f64(rng);
     return make_ray(origin, sample_location - origin, time);
 }
 // camera.rs:140-151

@@ -965,7 +965,10 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             else thr = thr / p;
         }
         if (!finished) {
-            double rsel = rng_f64(rng);
+            // :201 draws the selector even when there are no lights (p_light = 0: never below it) — then only the counter moves
+            double rsel = 1.0;
+            if (sc.n_lights == 0u) ++rng.draw;
+            else rsel = rng_f64(rng);
             bool ok = true;
             if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
             else ok = mat_sample(sc, *mp, hit, wo, rng, cam.two_pi_scale, tv, dir);

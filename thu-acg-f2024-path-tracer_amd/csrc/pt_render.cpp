@@ -191,7 +191,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         for (int i = 0; i < 3; ++i)
             zero = zero && dc.dof_right[i] == 0.0 && dc.dof_up[i] == 0.0 && !(dc.center[i] == 0.0 && std::signbit(dc.center[i]));
         dc.lens_zero = zero ? 1u : 0u;
-        dc.pad_ = 0;
+        // sphere.rs:64-66: center = p1 + (p2 - p1) * time; with p1 == p2 that is p1 + (+0) * time = p1 for every time in [0, 1)
+        dc.motionless = s->motionless && !exp_env("PT_DRAW_TIME") ? 1u : 0u;
     }
     if (dc.env_is_map) {
         if (cam->env_tex < 0 || (size_t)cam->env_tex >= s->tex.size() || s->tex[cam->env_tex].d.kind != TEX_IMAGE)

@@ -741,6 +741,9 @@ int pt::scene_build(pt_scene* s) {
     dev.view = v;
     s->n_prims = v.n_prims;
     s->n_mesh_entries = 0;
+    s->motionless = true;
+    for (const SphereD& sp : spheres)
+        for (int i = 0; i < 3; ++i) s->motionless = s->motionless && sp.p1[i] == sp.p2[i];
     for (const Entry& e : entries) s->n_mesh_entries += e.kind == ENTRY_MESH ? 1u : 0u;
     s->built = true;
     return 0;

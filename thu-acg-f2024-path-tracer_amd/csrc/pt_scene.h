@@ -66,6 +66,7 @@ struct pt_scene {
     bool built = false;
     uint32_t n_prims = 0;
     uint32_t n_mesh_entries = 0;   // world-level triangle meshes (picks the K2 variant)
+    bool motionless = false;       // no sphere moves (p1 == p2 everywhere): a ray's time never reaches an arithmetic result
     uint32_t stack_need = 0;       // worst-case traversal stack entries of this scene's BVHs
     uint32_t device_bvh_min_tris = 1u << 19;   // meshes with at least this many triangles get their BVH built on the GPU (0 = never)
     uint32_t n_device_blas = 0, device_blas_depth = 0;   // meshes of the last build that the GPU builder handled, deepest of them

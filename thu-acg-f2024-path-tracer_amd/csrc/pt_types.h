@@ -120,7 +120,7 @@ struct CamD {
     int32_t env_tex;
     uint32_t n_lights;
     uint32_t lens_zero;      // defocus radius 0 (dof_right = dof_up = 0, no -0.0 in center): the lens point is `center` exactly
-    uint32_t pad_;
+    uint32_t motionless;     // no moving sphere in the scene: Ray::time is drawn (camera.rs:165) but its value is never used
 };
 
 struct SceneD {
