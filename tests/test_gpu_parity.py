@@ -263,6 +263,22 @@ def test_kernel_forms_and_pool_sizes_agree(pt, ctx):
         _with_env({"PT_EXPERIMENT": "1", "PT_POOL_SLOTS": "0"}, lambda: render(0, 2))
     acc, st = _with_env({"PT_EXPERIMENT": "1", "PT_SLOTS_PER_PIXEL": "3"}, lambda: render(2, 6))   # an explicit option wins
     assert st.slots_per_pixel == 2
+    for env in ({"PT_ENTRYBOX_VIA_PRIMREF": "1"}, {"PT_DRAW_TIME": "1"}):   # walk records without the direct primitive index; Ray::time computed although nothing moves
+        acc, st = _with_env(dict(env, PT_EXPERIMENT="1"), lambda: render(1, 6))
+        np.testing.assert_array_equal(acc, ref, err_msg=str(env))
+    # scenes of quads and cuboids only (batch kernel, flat top level): with and without the (ray, primitive) pair passes
+    def render_room(sid):
+        gs = pt.Scene(ctx)
+        cam = gs.build_scene(sid, 64, 5)
+        acc, st = gs.render(cam, 9, 0, 5, slots_per_pixel=1)
+        gs.close()
+        return acc, st
+    for sid in (3, 7):
+        ref_room, st_room = render_room(sid)
+        for env in ({"PT_NO_FLAT_PAIRS": "1"}, {"PT_NO_FLAT_TLAS": "1"}, {"PT_ENTRYBOX_VIA_PRIMREF": "1"}):
+            acc, st = _with_env(dict(env, PT_EXPERIMENT="1"), lambda: render_room(sid))
+            np.testing.assert_array_equal(acc, ref_room, err_msg=f"scene {sid} {env}")
+            assert st.segments == st_room.segments
     ref40, st40 = render(1, 40)
     fin = np.isfinite(ref40)
     for env in ({}, {"PT_POOL_SLOTS": "4096"}, {"PT_POOL_SLOTS": "1000"}, {"PT_POOL_SLOTS": "70000", "PT_NO_FLAT_TLAS": "1"}):
@@ -288,6 +304,31 @@ def test_random_scenes_bit_exact(pt, det, ctx, seed):
     assert st.segments == cnt["segments"]
     np.testing.assert_array_equal(ga, oa)           # NaN/inf samples (reference quirks) included
     gs.close(); os_.close()
+
+
+@pytest.mark.parametrize("seed", [100, 101, 102, 103])
+def test_random_scenes_without_meshes_bit_exact(pt, det, ctx, seed):
+    """Fuzz of the batch K2 with a flat top level: spheres (moving ones too), quads and instanced cuboids only — the scenes whose
+    cuboid faces go through the dense (ray, primitive) pair passes (flat_top_level) and whose LDS minimum-t / maximum-id
+    protocol must reproduce consider()'s closest-hit rule; checked against the same scene without the pair passes."""
+    spec = random_scene(seed, with_mesh=False, sphere_light=(seed % 2 == 1), n_objects=8 + seed % 12)
+    gs, os_ = pt.Scene(ctx), det.Scene()
+    gres, ores = spec.replay(gs), spec.replay(os_)
+    gcam, ocam = spec.make_camera(pt.Camera, gres), spec.make_camera(det.Camera, ores)
+    ga, st = gs.render(gcam, 11, 0, 6, slots_per_pixel=1)
+    oa, cnt = os_.render(ocam, 11, 0, 6)
+    assert st.extend_variant == 1                                    # batch kernel
+    assert st.segments == cnt["segments"]
+    np.testing.assert_array_equal(ga, oa)
+    gs.close(); os_.close()
+
+    def again():
+        g2 = pt.Scene(ctx)
+        cam2 = spec.make_camera(pt.Camera, spec.replay(g2))
+        a, _ = g2.render(cam2, 11, 0, 6, slots_per_pixel=1)
+        g2.close()
+        return a
+    np.testing.assert_array_equal(_with_env({"PT_EXPERIMENT": "1", "PT_NO_FLAT_PAIRS": "1"}, again), ga)
 
 
 def _all_light_kinds_scene():

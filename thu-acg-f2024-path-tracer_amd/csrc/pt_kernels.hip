@@ -599,11 +599,13 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
 #ifdef PT_STAMPS
     if (threadIdx.x < 8) g_prof[CLASS_DEAD][threadIdx.x] = 0ull;
 #endif
+    // (the next window's index is drawn before the barrier that ends a window and published by it: see k_shade)
+    if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_extend, 1ull); s_nrays = 0; s_next = 0; }
+    __syncthreads();
     for (;;) {
-        if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_extend, 1ull); s_nrays = 0; s_next = 0; }
-        __syncthreads();
-        if (s_win >= n_windows) break;
-        const uint32_t wbase = s_win * EXT_WINDOW;
+        const uint32_t win = s_win;
+        if (win >= n_windows) break;
+        const uint32_t wbase = win * EXT_WINDOW;
         PT_STAMP(e0);
         // ---- phase A: top level only ---------------------------------------------------------------
         // the ray of the NEXT chunk is requested before this chunk's traversal starts: with three waves per
@@ -793,6 +795,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
 #pragma unroll
             for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) stnt(&pool.hit_prim[wbase + (uint32_t)j * BLOCK + threadIdx.x], word[j]);
         }
+        if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_extend, 1ull); s_nrays = 0; s_next = 0; }   // all of this window's uses are behind the barrier above
         __syncthreads();   // LDS lists are reused by the next window
     }
     if (nseg) atomicAdd(&cnt->segments, nseg);
@@ -1120,12 +1123,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
         const int wave = (int)(threadIdx.x >> 6);
         __shared__ uint32_t s_win;
         const uint32_t n_windows = pool.n_alloc / SORT_WINDOW;
+        // The window index of the NEXT round is drawn by thread 0 when its wave has run out of groups and published by the
+        // barrier that ends the window anyway: no barrier of its own, and the atomic's round trip (2-3 k cycles the whole
+        // block used to sit out at the top of every window) runs while the other waves finish their groups.
+        if (threadIdx.x == 0) s_win = (uint32_t)atomicAdd(&cnt->win_shade, 1ull);
+        __syncthreads();
         for (;;) {
             PT_STAMP(w0);
-            if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_shade, 1ull); s_next = 0; }
-            __syncthreads();
-            if (s_win >= n_windows) break;
-            const uint32_t wbase = s_win * SORT_WINDOW;
+            const uint32_t win = s_win;
+            if (win >= n_windows) break;
+            if (threadIdx.x == 0) s_next = 0;      // (every wave is past the previous window's last grab; the first one of this window comes three barriers later)
+            const uint32_t wbase = win * SORT_WINDOW;
             // classify; STABLE counting sort (slot order is kept inside a class, so the work items a
             // wave dequeues — consecutive pixels of one tile — stay together in a group).
             uint32_t keys = 0;   // 8 x 4-bit class keys: K2 left the class in the top bits of its result word
@@ -1149,14 +1157,21 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 }
             }
             __syncthreads();
-            if (threadIdx.x < NCLASS) {   // one thread per class: exclusive prefix over the groups in slot order
-                uint32_t acc = 0;
-                for (int g = 0; g < NGRP; ++g) {
-                    const uint32_t c = s_cnt[threadIdx.x][g];
-                    s_cnt[threadIdx.x][g] = acc;
-                    acc += c;
+            // exclusive prefix over the groups in slot order, per class: NGRP = 32 lanes scan one class with five shuffles (the
+            // round-1 form — one thread per class walking its 32 counts through LDS, a chain of 32 dependent reads the other
+            // 245 threads waited for at the barrier — was a fifth of the sort's time); the block's waves share the classes
+            static_assert(NGRP == 32, "one half-wave per class");
+            for (uint32_t k = (uint32_t)wave * 2u + (uint32_t)(lane >> 5); k < NCLASS; k += (BLOCK / 64) * 2u) {
+                const int g = lane & 31;
+                const uint32_t c = s_cnt[k][g];
+                uint32_t incl = c;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 32);
+                    if (g >= d) incl += up;
                 }
-                s_hist[threadIdx.x] = acc;
+                s_cnt[k][g] = incl - c;
+                if (g == 31) s_hist[k] = incl;
             }
             __syncthreads();
             uint32_t class_base[NCLASS];
@@ -1235,6 +1250,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 staged = staged_next;
             }
             PT_STAMP(w2);
+            if (threadIdx.x == 0) s_win = (uint32_t)atomicAdd(&cnt->win_shade, 1ull);   // everybody read s_win before this window's first barrier
             __syncthreads();   // LDS is reused by the next window
 #ifdef PT_STAMPS
             PT_STAMP(w3);

@@ -707,7 +707,7 @@ int pt::scene_build(pt_scene* s) {
                     const PrimRef& pk = prims[e.first_prim + k];
                     direct = direct && (pk.kind & 0xFFu) == (p0.kind & 0xFFu) && pk.index == p0.index + k && pk.inst == e.inst;
                 }
-                if (direct) {
+                if (direct && !exp_env("PT_ENTRYBOX_VIA_PRIMREF")) {
                     eb.prim_kind = p0.kind & 0xFFu;
                     eb.prim_index = p0.index;
                 }
