@@ -189,8 +189,9 @@ struct TexVals {
 PT_DEV TexVals fetch_tex(const SceneD& sc, const MatD& m, const HitD& h) {
     TexVals tv{V3{0.0, 0.0, 0.0}, 0.0};
     const uint32_t k = m.kind;
-    if (k == MAT_DIFFUSE || k == MAT_METAL || k == MAT_PRINCIPLED || k == MAT_LIGHT) tv.color = tex_rgb(sc, m.color_tex, h.u, h.v, h.point);
-    if (k == MAT_METAL || k == MAT_GLASS) tv.rough = tex_f(sc, m.rough_tex, h.point);
+    if (k == MAT_DIFFUSE || k == MAT_METAL || k == MAT_PRINCIPLED || k == MAT_LIGHT)
+        tv.color = m.color_solid ? V3{m.color_v[0], m.color_v[1], m.color_v[2]} : tex_rgb(sc, m.color_tex, h.u, h.v, h.point);
+    if (k == MAT_METAL || k == MAT_GLASS) tv.rough = m.rough_solid ? m.rough_v : tex_f(sc, m.rough_tex, h.point);
     return tv;   // MAT_MIX: its children fetch their own (mat_sample / mat_pdf_eval)
 }
 

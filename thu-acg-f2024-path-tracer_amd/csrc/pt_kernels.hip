@@ -538,7 +538,7 @@ PT_DEV unsigned long long stamp() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
-__shared__ unsigned long long g_prof[N_CLASSES + 1][8];
+__shared__ unsigned long long g_prof[N_CLASSES + 1][PROF_COLS];
 #define PT_STAMP(i) const unsigned long long t_##i = stamp()
 #define PT_STAMP_VAR(i) unsigned long long t_##i = 0
 #define PT_STAMP_SET(i) t_##i = stamp()
@@ -995,6 +995,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         ++bounce;
         if (bounce >= cam.max_depth) finished = parked = true;         // loop bound :177
     }
+#ifdef PT_STAMPS
+    const unsigned long long prof_live = __ballot(live), prof_hit = __ballot(is_hit), prof_dir = __ballot(have_dir);
+#endif
     PT_STAMP(2);
     // ---- phase C: finished paths accumulate (camera.rs:107) and draw their next work item ------------------------------------
     uint32_t next_pixel = pixel, next_sample = 0, next_row = 0, next_col = 0;
@@ -1040,6 +1043,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         more = next_sample < pool.spp_end;
     }
     if (!fetched) prefetch();                                          // P2: behind the dequeue, in front of the regeneration arithmetic
+#ifdef PT_STAMPS
+    const unsigned long long prof_regen = __ballot(alive && finished && more && !next_idle && !(parked && pool.dynamic));
+#endif
     PT_STAMP(3);
     // ---- phase D: regeneration in place, stores -----------------------------------------------------------------------------
     if (alive && finished) {
@@ -1074,6 +1080,10 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     PT_STAMP(4);
     if (lane == 0) {   // block-local sums in LDS (global atomics here would themselves be what the next group waits for)
         atomicAdd(&g_prof[prof_class][0], 1ull);
+        atomicAdd(&g_prof[prof_class][8], (unsigned long long)__popcll(prof_live));
+        atomicAdd(&g_prof[prof_class][9], (unsigned long long)__popcll(prof_hit));
+        atomicAdd(&g_prof[prof_class][10], (unsigned long long)__popcll(prof_dir));
+        atomicAdd(&g_prof[prof_class][11], (unsigned long long)__popcll(prof_regen));
         atomicAdd(&g_prof[prof_class][1], (t_a1 ? t_a1 : t_a2) - t_1);   // records unpacked, hit reconstructed
         atomicAdd(&g_prof[prof_class][6], t_a2 - (t_a1 ? t_a1 : t_a2));  // environment / textures
         atomicAdd(&g_prof[prof_class][7], t_b1 - t_a2);                  // roulette + direction
@@ -1101,7 +1111,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
     unsigned long long n_done = 0, n_died = 0;
     const int lane = (int)(threadIdx.x & 63u);
 #ifdef PT_STAMPS
-    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * 8; i += BLOCK) (&g_prof[0][0])[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * PROF_COLS; i += BLOCK) (&g_prof[0][0])[i] = 0ull;
     __syncthreads();
 #endif
     uint32_t shard = blockIdx.x % WORK_SHARDS;   // work-counter shard this wave draws from (wave-uniform; moves on when it runs dry)
@@ -1267,7 +1277,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
     if (n_died) atomicSub(&cnt->alive, n_died);
 #ifdef PT_STAMPS
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * 8; i += BLOCK)
+    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * PROF_COLS; i += BLOCK)
         if ((&g_prof[0][0])[i]) atomicAdd(&cnt->prof[0][0] + i, (&g_prof[0][0])[i]);
 #endif
 }

@@ -392,7 +392,9 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
             else if (p[0] && c < N_CLASSES)
                 fprintf(stderr, "[pt prof] %-10s n %10llu  body %8.0f = hit %7.0f + env/tex %7.0f + direction %7.0f + pdf/eval/ray %7.0f  dequeue %8.0f  regen+store %8.0f  whole %8.0f (cycles per wave-group)\n",
                         names[c], p[0], (double)p[2] / p[0], (double)p[1] / p[0], (double)p[6] / p[0], (double)p[7] / p[0], (double)(p[2] - p[1] - p[6] - p[7]) / p[0],
-                        (double)p[3] / p[0], (double)p[4] / p[0], (double)p[5] / p[0]);
+                        (double)p[3] / p[0], (double)p[4] / p[0], (double)p[5] / p[0]),
+                fprintf(stderr, "[pt prof] %-10s   lanes per group: live %5.1f  on a surface %5.1f  with a next direction %5.1f  regenerated %5.1f\n", names[c], (double)p[8] / p[0],
+                        (double)p[9] / p[0], (double)p[10] / p[0], (double)p[11] / p[0]);
             else if (p[0])
                 fprintf(stderr, "[pt prof] WINDOW     n %10llu  sort %8.0f  shade %8.0f  barrier wait %8.0f  groups %8.0f  record wait %8.0f (cycles per window and wave)\n", p[0],
                         (double)p[1] / p[0], (double)p[2] / p[0], (double)p[3] / p[0], (double)p[4] / p[0], (double)p[5] / p[0]);

@@ -685,6 +685,20 @@ int pt::scene_build(pt_scene* s) {
             t.flat = solid ? 1u : 0u;
             for (int c = 0; c < 3; ++c) { t.c1[c] = solid ? a.v[c] : 0.0; t.c2[c] = solid ? b.v[c] : 0.0; }
         }
+    std::vector<MatD> mats = s->mats;   // solid textures' values into the material records (MatD::color_solid)
+    for (MatD& m : mats) {
+        m.color_solid = m.rough_solid = 0u;
+        const bool has_color = m.kind == MAT_DIFFUSE || m.kind == MAT_METAL || m.kind == MAT_PRINCIPLED || m.kind == MAT_LIGHT;
+        const bool has_rough = m.kind == MAT_METAL || m.kind == MAT_GLASS;
+        if (has_color && m.color_tex >= 0 && (size_t)m.color_tex < tex.size() && tex[m.color_tex].kind == TEX_SOLID_RGB && !exp_env("PT_NO_SOLID_IN_MAT")) {
+            m.color_solid = 1u;
+            for (int c = 0; c < 3; ++c) m.color_v[c] = tex[m.color_tex].v[c];
+        }
+        if (has_rough && m.rough_tex >= 0 && (size_t)m.rough_tex < tex.size() && tex[m.rough_tex].kind == TEX_SOLID_F && !exp_env("PT_NO_SOLID_IN_MAT")) {
+            m.rough_solid = 1u;
+            m.rough_v = tex[m.rough_tex].v[0];
+        }
+    }
     std::vector<EntryBox> entry_box;   // tlas_items[i] is entry i (built in entry order, before the builder permutes them)
     for (int pass = 0; pass < 2; ++pass)   // spheres / quads / cuboids first: their hits trim the mesh boxes
         for (size_t i = 0; i < entry_boxes.size(); ++i) {
@@ -719,7 +733,7 @@ int pt::scene_build(pt_scene* s) {
     bool ok = upload(dev, nodes, v.nodes) && upload(dev, entries, v.entries) && upload(dev, prims, v.prims) &&
               upload(dev, spheres, v.spheres) && upload(dev, quads, v.quads) && upload(dev, tris, v.tris) &&
               upload(dev, tri_gid, v.tri_gid) && upload(dev, insts, v.insts) && upload(dev, tex, v.tex) &&
-              upload(dev, s->mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, lights, v.lights) && upload(dev, entry_box, v.entry_box);
+              upload(dev, mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, lights, v.lights) && upload(dev, entry_box, v.entry_box);
     if (ok && any_attr) ok = upload(dev, tri_attr, v.tri_attr);
     if (!ok) {
         dev.release();

@@ -108,6 +108,11 @@ struct MatD {
     // ior, spec_trans, sheen, sheen_tint, clearcoat, clearcoat_gloss
     double p[11];
     double lobe_w[4], lobe_p[4], alpha_g;   // principled.rs:75-100, precomputed on the host
+    // A SOLID colour / roughness texture's value, copied here by the scene build: the material record then answers without the
+    // texture descriptor — one level less in k_shade's chain of dependent loads (primitive -> material -> texture). Filled for
+    // MAT_DIFFUSE / METAL / GLASS / PRINCIPLED / LIGHT; a mix's children are looked up the long way.
+    uint32_t color_solid, rough_solid;
+    double color_v[3], rough_v;
 };
 
 // ---- camera --------------------------------------------------------------------------
@@ -215,6 +220,7 @@ struct PoolD {
 // (65k per launch at 4M resident paths), which alone would cost ~0.75 ms per launch. Shard s hands
 // out the work items w with w % WORK_SHARDS == s; a block always uses shard blockIdx.x % WORK_SHARDS.
 constexpr uint32_t WORK_SHARDS = 64;
+constexpr int PROF_COLS = 12;   // diagnostic build (-DPT_STAMPS): columns of the per-class profile
 struct CountersD {
     unsigned long long alive;        // slots still rendering
     unsigned long long segments;     // extend() calls on live paths
@@ -226,7 +232,7 @@ struct CountersD {
     unsigned long long pad[11];
     // diagnostic builds only (-DPT_STAMPS, tools/build_variant.sh): wave-cycle sums per k_shade class
     // [class][0 groups, 1 record-load wait, 2 body, 3 work dequeue, 4 regeneration + stores, 5 whole], [N_CLASSES][..] = window phases
-    unsigned long long prof[N_CLASSES + 1][8];
+    unsigned long long prof[N_CLASSES + 1][PROF_COLS];
     struct alignas(128) Shard { unsigned long long next; unsigned long long pad[15]; } work[WORK_SHARDS];
 };
 
