@@ -68,12 +68,13 @@ def cpu_baseline(scene_id, width, seconds, images):
     s = orc.Scene()
     cam = s.build_scene(scene_id, width, 1, images=images)     # BVH build is not timed (camera.rs:80 starts after it)
     h = orc.image_height(cam)
+    s.render(cam, 1, 0, 1)                   # untimed: thread pool start-up, first touch of the scene
     t = time.time()
-    s.render(cam, 1, 0, 1)
-    t1 = max(time.time() - t, 1e-3)
-    spp = int(max(1, min(64, round(seconds / t1))))
+    s.render(cam, 1, 1, 3)
+    per_spp = max((time.time() - t) / 2.0, 1e-3)
+    spp = int(max(1, min(256, round(seconds / per_spp))))
     t = time.time()
-    _, cnt = s.render(cam, 1, 1, 1 + spp)
+    _, cnt = s.render(cam, 1, 3, 3 + spp)
     dt = time.time() - t
     s.close()
     cores = os.cpu_count()

@@ -105,6 +105,8 @@ for k in ("k_extend", "k_shade"):
         d["int32_share_of_valu_insts"] = m(k, "SQ_INSTS_VALU_INT32") / m(k, "SQ_INSTS_VALU")
     o["derived"] = d
 out["resident_paths"] = slots
+out["source"] = (f"tools/run_profiles.sh {tag}: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_*; --kernel-trace only) over "
+                 "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`")
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
 for k in ("k_extend", "k_shade"):
