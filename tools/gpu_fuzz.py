@@ -1,5 +1,5 @@
 """One-off soak: random scenes (tests/common.random_scene) GPU vs oracle (det math), bit-exact, for a seed range.
-    python tools/gpu_fuzz.py 4 40 [cam]
+    python tools/gpu_fuzz.py 4 40 [cam] [nomesh]     (nomesh: spheres / quads / cuboids only -> the batch K2 and its pair passes)
 """
 import importlib, os, sys
 import numpy as np
@@ -12,8 +12,8 @@ orc.set_math_mode(True)
 ctx = pt.Context(0)
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
-    spec = random_scene(seed, sphere_light=(seed % 2 == 1), n_objects=6 + seed % 9)
-    if len(sys.argv) > 3 and sys.argv[3] == "cam":        # also randomise the camera
+    spec = random_scene(seed, with_mesh="nomesh" not in sys.argv[3:], sphere_light=(seed % 2 == 1), n_objects=6 + seed % (16 if "nomesh" in sys.argv[3:] else 9))
+    if "cam" in sys.argv[3:]:        # also randomise the camera
         r = np.random.default_rng(seed)
         spec.camera.update(vfov=float(r.uniform(20, 95)), defocus_angle=float(r.uniform(0, 3)), focal_length=float(r.uniform(3, 9)),
                            aspect_ratio=float(r.choice([1.0, 1.5, 0.7, 16 / 9])), image_width=int(r.integers(33, 80)),
