@@ -829,13 +829,14 @@ struct SlotIn {
     RayD ray;
 };
 // straight from the pool (first group of a window, static mode, unsorted K3). `enable` = false: bystander lane.
-PT_DEV SlotIn load_slot_global(const PoolD& pool, uint32_t s, bool enable) {
+// `hw_known`: the caller has the slot's result word already (k_shade's sort keeps the window's words in LDS).
+PT_DEV SlotIn load_slot_global(const PoolD& pool, uint32_t s, bool enable, const uint32_t* hw_known = nullptr) {
     SlotIn in{};
     in.bounce = enable ? pool.bounce[s] : SLOT_DEAD;
     if (in.bounce < SLOT_IDLE) {
         in.thr = load_path(pool, s, in.pixel);
         in.ray = load_ray(pool, s, in.sample, in.draw);
-        in.hw = pool.hit_prim[s];
+        in.hw = hw_known ? *hw_known : pool.hit_prim[s];
     }
     return in;
 }
@@ -843,7 +844,7 @@ PT_DEV SlotIn load_slot_global(const PoolD& pool, uint32_t s, bool enable) {
 // from HBM to LDS without passing through (or occupying) a single vector register, which is the only way this kernel, at its
 // 256-register limit, can have the NEXT group's 6.5 KB in flight while it computes on the current one. Layout: chunk c of
 // lane l at stage[c][l] (lane-linear, as the instruction writes: M0 base + lane * size): RayRec = chunks 0..3, PathRec = 4..5,
-// chunk 6 = result words (64 x 4 B) then states (64 x 4 B). Must be executed by ALL 64 lanes (wave-uniform control flow).
+// chunk 6 = states (64 x 4 B). Must be executed by ALL 64 lanes (wave-uniform control flow).
 constexpr int STAGE_CHUNKS = 7;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -856,15 +857,14 @@ PT_DEV void stage_fetch(const PoolD& pool, uint32_t s, uint4 (*stage)[64]) {
     __builtin_amdgcn_global_load_lds((glb_ptr)(r + 48), (lds_ptr)&stage[3][0], 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr)(p), (lds_ptr)&stage[4][0], 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr)(p + 16), (lds_ptr)&stage[5][0], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr)&pool.hit_prim[s], (lds_ptr)&stage[6][0], 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr)&pool.bounce[s], (lds_ptr)&stage[6][16], 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)&pool.bounce[s], (lds_ptr)&stage[6][0], 4, 0, 0);   // (the result word comes from the sort's copy in LDS)
 }
 // the staged records of this lane (after the issuing wave's s_waitcnt vmcnt(0): nothing else orders an LDS read behind an LDS-DMA)
-PT_DEV SlotIn load_slot_stage(const uint4 (*stage)[64], int lane, bool enable) {
+PT_DEV SlotIn load_slot_stage(const uint4 (*stage)[64], int lane, bool enable, uint32_t hw) {
     SlotIn in{};
     const uint32_t* words = reinterpret_cast<const uint32_t*>(&stage[6][0]);
-    in.bounce = enable ? words[64 + lane] : SLOT_DEAD;
-    in.hw = words[lane];
+    in.bounce = enable ? words[lane] : SLOT_DEAD;
+    in.hw = hw;
     const uint4 a = stage[0][lane], b = stage[1][lane], c = stage[2][lane], d = stage[3][lane], e = stage[4][lane], f = stage[5][lane];
     auto f64 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
     in.ray = RayD{V3{f64(a.x, a.y), f64(a.z, a.w), f64(b.x, b.y)}, V3{f64(b.z, b.w), f64(c.x, c.y), f64(c.z, c.w)}, f64(d.x, d.y)};
@@ -1125,6 +1125,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
         }
     } else {
         __shared__ uint16_t s_perm[SORT_WINDOW];
+        __shared__ uint32_t s_hw[SORT_WINDOW];                  //  8 KB: K2's result words of the window
         constexpr uint32_t NCLASS = N_CLASSES, K_DEAD = CLASS_DEAD;   // miss, one per material kind, idle, dead
         __shared__ uint32_t s_cnt[NCLASS][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
         __shared__ uint32_t s_hist[NCLASS], s_next;
@@ -1149,7 +1150,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             uint32_t keys = 0;   // 8 x 4-bit class keys: K2 left the class in the top bits of its result word
             uint32_t rank[PER];
 #pragma unroll
-            for (int j = 0; j < PER; ++j) keys |= (pool.hit_prim[wbase + (uint32_t)j * BLOCK + threadIdx.x] >> HIT_CLASS_SHIFT) << (4 * j);
+            for (int j = 0; j < PER; ++j) {
+                // the window's result words stay in LDS: the groups take theirs from here instead of gathering 4 bytes per lane
+                // from the pool a second time (a 32-byte sector each)
+                const uint32_t hw = pool.hit_prim[wbase + (uint32_t)j * BLOCK + threadIdx.x];
+                s_hw[(uint32_t)j * BLOCK + threadIdx.x] = hw;
+                keys |= (hw >> HIT_CLASS_SHIFT) << (4 * j);
+            }
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 const uint32_t key = (keys >> (4 * j)) & 15u;
@@ -1228,11 +1235,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 bool enable;
                 const uint32_t s = slot_of(g, enable);
                 SlotIn in;
+                const uint32_t hw = s_hw[s - wbase];
                 if (staged) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed (and this wave's older stores with it)
-                    in = load_slot_stage(stage, lane, enable);
+                    in = load_slot_stage(stage, lane, enable, hw);
                 } else {
-                    in = load_slot_global(pool, s, enable);
+                    in = load_slot_global(pool, s, enable, &hw);
                 }
                 PT_DRAIN();
 #ifdef PT_STAMPS
