@@ -55,17 +55,18 @@ PT_DEV void store_ray(const PoolD& pool, uint32_t s, const RayD& r, uint32_t sam
     p[2] = d2v{r.d.y, r.d.z};
     *reinterpret_cast<u4v*>(p + 3) = u4v{(uint32_t)__double2loint(r.time), (uint32_t)__double2hiint(r.time), sample, draw};
 }
-PT_DEV V3 load_path(const PoolD& pool, uint32_t s, uint32_t& pixel) {
+PT_DEV V3 load_path(const PoolD& pool, uint32_t s, uint32_t& pixel, uint32_t& bounce) {
     const d2v* p = reinterpret_cast<const d2v*>(&pool.path[s]);
     const d2v a = p[0];
     const u4v b = *reinterpret_cast<const u4v*>(p + 1);
     pixel = b.z;
+    bounce = b.w;
     return V3{a.x, a.y, __hiloint2double((int)b.y, (int)b.x)};
 }
-PT_DEV void store_path(const PoolD& pool, uint32_t s, V3 thr, uint32_t pixel) {
+PT_DEV void store_path(const PoolD& pool, uint32_t s, V3 thr, uint32_t pixel, uint32_t bounce) {
     d2v* p = reinterpret_cast<d2v*>(&pool.path[s]);
     p[0] = d2v{thr.x, thr.y};
-    *reinterpret_cast<u4v*>(p + 1) = u4v{(uint32_t)__double2loint(thr.z), (uint32_t)__double2hiint(thr.z), pixel, 0u};
+    *reinterpret_cast<u4v*>(p + 1) = u4v{(uint32_t)__double2loint(thr.z), (uint32_t)__double2hiint(thr.z), pixel, bounce};
 #if PT_PATHREC_BYTES == 64
     p[2] = d2v{0.0, 0.0};                         // the record is one 64-B sector: write all of it
     p[3] = d2v{0.0, 0.0};
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
             pool.rx[s] = 0.0; pool.ry[s] = 0.0; pool.rz[s] = 0.0;
         }
         pool.hit_prim[s] = (CLASS_DEAD << HIT_CLASS_SHIFT) | HIT_ID_MASK;   // overwritten by the first K2 launch
-        store_path(pool, s, V3{1.0, 1.0, 1.0}, pixel);
+        store_path(pool, s, V3{1.0, 1.0, 1.0}, pixel, 0u);
         if (!has_work || idle) {
             pool.bounce[s] = idle ? SLOT_IDLE : SLOT_DEAD;
             store_ray(pool, s, RayD{}, sample, 0u);
@@ -550,6 +551,10 @@ __shared__ unsigned long long g_prof[N_CLASSES + 1][PROF_COLS];
 #define PT_DRAIN()
 #endif
 
+#ifndef PT_K2_PREFETCH
+#define PT_K2_PREFETCH 0              // 1: phase A holds the next chunk's ray in registers while it walks the current one — the round-1 form,
+#endif                               // which at 128 registers costs 60 B of spills per lane: without it K2 runs 7 % faster and writes 0.46 GB less
+
 constexpr int EXT_WINDOW = 2048;   // slots per block window
 constexpr uint32_t REFILL_MIN = 16;   // idle lanes that trigger a refill of the wave in phase B
 constexpr int EXT_CAND = 768;      // candidate list of a window (LDS); a fuller window walks the rest in phase A
@@ -608,13 +613,15 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         const uint32_t wbase = win * EXT_WINDOW;
         PT_STAMP(e0);
         // ---- phase A: top level only ---------------------------------------------------------------
-        // the ray of the NEXT chunk is requested before this chunk's traversal starts: with three waves per
-        // SIMD nothing else hides the 2-3 us an HBM fetch takes
+        // (PT_K2_PREFETCH: the ray of the NEXT chunk requested before this chunk's traversal starts)
+#if PT_K2_PREFETCH
         uint32_t state_next = pool.bounce[wbase + threadIdx.x];
         RayD r_next{};
         if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + threadIdx.x);
+#endif
         for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) {
             const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x;
+#if PT_K2_PREFETCH
             const uint32_t state = state_next;
             const bool alive = state < SLOT_IDLE;
             const RayD r = r_next;
@@ -622,6 +629,12 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 state_next = pool.bounce[wbase + sl + BLOCK];
                 if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + sl + BLOCK);
             }
+#else
+            const uint32_t state = pool.bounce[wbase + sl];
+            const bool alive = state < SLOT_IDLE;
+            RayD r{};
+            if (alive) r = load_ray(pool, wbase + sl);
+#endif
             uint32_t n_my = 0, items = 0xFFFFFFFFu;
             RayF f{};
             Closest best{D_INF, HIT_NONE};
@@ -830,22 +843,30 @@ struct SlotIn {
 };
 // straight from the pool (first group of a window, static mode, unsorted K3). `enable` = false: bystander lane.
 // `hw_known`: the caller has the slot's result word already (k_shade's sort keeps the window's words in LDS).
+// Whether a slot is alive, idle or dead is in the class of K2's result word (K2 read PoolD::bounce, the slots' STATE array,
+// coalesced); the bounce NUMBER of a live path travels in its PathRec. k_shade therefore never reads the state array and writes
+// it only when a slot changes state (parked, regenerated from idle, dead) — it used to gather 4 bytes per lane from it and
+// scatter 4 bytes per lane back on every bounce of every path.
+PT_DEV uint32_t state_of_class(uint32_t hw) {
+    const uint32_t cls = hw >> HIT_CLASS_SHIFT;
+    return cls == CLASS_IDLE ? SLOT_IDLE : cls == CLASS_DEAD ? SLOT_DEAD : 0u;
+}
 PT_DEV SlotIn load_slot_global(const PoolD& pool, uint32_t s, bool enable, const uint32_t* hw_known = nullptr) {
     SlotIn in{};
-    in.bounce = enable ? pool.bounce[s] : SLOT_DEAD;
+    in.hw = hw_known ? *hw_known : pool.hit_prim[s];
+    in.bounce = enable ? state_of_class(in.hw) : SLOT_DEAD;
     if (in.bounce < SLOT_IDLE) {
-        in.thr = load_path(pool, s, in.pixel);
+        in.thr = load_path(pool, s, in.pixel, in.bounce);
         in.ray = load_ray(pool, s, in.sample, in.draw);
-        in.hw = hw_known ? *hw_known : pool.hit_prim[s];
     }
     return in;
 }
 // Asynchronous fetch of a group's records into the wave's LDS staging area: `global_load_lds` (LDS-DMA) — the data goes
 // from HBM to LDS without passing through (or occupying) a single vector register, which is the only way this kernel, at its
-// 256-register limit, can have the NEXT group's 6.5 KB in flight while it computes on the current one. Layout: chunk c of
-// lane l at stage[c][l] (lane-linear, as the instruction writes: M0 base + lane * size): RayRec = chunks 0..3, PathRec = 4..5,
-// chunk 6 = states (64 x 4 B). Must be executed by ALL 64 lanes (wave-uniform control flow).
-constexpr int STAGE_CHUNKS = 7;
+// 256-register limit, can have the NEXT group's 6 KB in flight while it computes on the current one. Layout: chunk c of
+// lane l at stage[c][l] (lane-linear, as the instruction writes: M0 base + lane * size): RayRec = chunks 0..3, PathRec = 4..5.
+// Must be executed by ALL 64 lanes (wave-uniform control flow).
+constexpr int STAGE_CHUNKS = 6;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 PT_DEV void stage_fetch(const PoolD& pool, uint32_t s, uint4 (*stage)[64]) {
@@ -857,13 +878,10 @@ PT_DEV void stage_fetch(const PoolD& pool, uint32_t s, uint4 (*stage)[64]) {
     __builtin_amdgcn_global_load_lds((glb_ptr)(r + 48), (lds_ptr)&stage[3][0], 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr)(p), (lds_ptr)&stage[4][0], 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr)(p + 16), (lds_ptr)&stage[5][0], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr)&pool.bounce[s], (lds_ptr)&stage[6][0], 4, 0, 0);   // (the result word comes from the sort's copy in LDS)
 }
 // the staged records of this lane (after the issuing wave's s_waitcnt vmcnt(0): nothing else orders an LDS read behind an LDS-DMA)
 PT_DEV SlotIn load_slot_stage(const uint4 (*stage)[64], int lane, bool enable, uint32_t hw) {
     SlotIn in{};
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(&stage[6][0]);
-    in.bounce = enable ? words[lane] : SLOT_DEAD;
     in.hw = hw;
     const uint4 a = stage[0][lane], b = stage[1][lane], c = stage[2][lane], d = stage[3][lane], e = stage[4][lane], f = stage[5][lane];
     auto f64 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
@@ -872,6 +890,8 @@ PT_DEV SlotIn load_slot_stage(const uint4 (*stage)[64], int lane, bool enable, u
     in.draw = d.w;
     in.thr = V3{f64(e.x, e.y), f64(e.z, e.w), f64(f.x, f.y)};
     in.pixel = f.z;
+    const uint32_t state = state_of_class(hw);
+    in.bounce = !enable ? SLOT_DEAD : state < SLOT_IDLE ? f.w : state;   // the bounce number rides in the PathRec
     return in;
 }
 struct NoPrefetch {
@@ -1069,10 +1089,11 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         }
     }
     if (alive) {
-        pool.bounce[s] = bounce;
+        const uint32_t state_new = bounce < SLOT_IDLE ? 0u : bounce, state_old = was_idle ? SLOT_IDLE : 0u;
+        if (state_new != state_old) pool.bounce[s] = state_new;       // the state array changes only with the slot's state
         if (bounce < SLOT_IDLE) {
             store_ray(pool, s, ray, sample, rng.draw);
-            store_path(pool, s, thr, pixel);
+            store_path(pool, s, thr, pixel, bounce);
             if (!pool.dynamic) { pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z; }
         }
     }
@@ -1129,7 +1150,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
         constexpr uint32_t NCLASS = N_CLASSES, K_DEAD = CLASS_DEAD;   // miss, one per material kind, idle, dead
         __shared__ uint32_t s_cnt[NCLASS][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
         __shared__ uint32_t s_hist[NCLASS], s_next;
-        __shared__ uint4 s_stage[BLOCK / 64][STAGE_CHUNKS][64];   // 28 KB: one staging area per wave (stage_fetch)
+        __shared__ uint4 s_stage[BLOCK / 64][STAGE_CHUNKS][64];   // 24 KB: one staging area per wave (stage_fetch)
         constexpr int PER = SORT_WINDOW / BLOCK, NGRP = SORT_WINDOW / 64;
         const int wave = (int)(threadIdx.x >> 6);
         __shared__ uint32_t s_win;
