@@ -108,7 +108,7 @@ PT_DEV double ggx_G1(V3 w, double roughness) {
 PT_DEV double gtr1_D(double abs_cos_theta, double alpha_g) {
     double alpha2 = alpha_g * alpha_g;
     double t = 1.0 + (alpha2 - 1.0) * abs_cos_theta * abs_cos_theta;
-    return (alpha2 - 1.0) / (D_PI * t * detmath::log2(alpha2));
+    return (alpha2 - 1.0) / (D_PI * t * dev_log2(alpha2));
 }
 PT_DEV V3 cosine_sample_hemisphere(Rng& rng, double two_pi_scale) {   // sampling.rs:18-24
     uint64_t a, b;
@@ -144,7 +144,7 @@ PT_DEV V3 gtr1_sample_microfacet_normal(double alpha, Rng& rng) {   // sampling.
     rng_u64x2(rng, ua, ub);
     double e1 = u64_to_unit(ua), e2 = u64_to_unit(ub);
     double alpha2 = alpha * alpha;
-    double cos_theta = (1.0 - detmath::pow(alpha2, 1.0 - e1)) / (1.0 - alpha2);
+    double cos_theta = (1.0 - dev_pow(alpha2, 1.0 - e1)) / (1.0 - alpha2);
     double sin_theta = sqrt(fmax(1.0 - cos_theta * cos_theta, 0.0));
     double phi = 2.0 * D_PI * e2;
     const SinCos sc_phi = dev_sincos(phi);

@@ -85,6 +85,8 @@ PT_DM_CALL SinCos dev_sincos(double x) {
 }
 PT_DM_CALL double dev_acos(double x) { return detmath::acos(x); }
 PT_DM_CALL double dev_atan2(double y, double x) { return detmath::atan2(y, x); }
+PT_DM_CALL double dev_pow(double x, double y) { return detmath::pow(x, y); }       // GTR1 sampling only (sampling.rs:132): inlined, its
+PT_DM_CALL double dev_log2(double x) { return detmath::log2(x); }                  // constant tables were k_shade's last spills
 
 // Wave-uniform read of read-only scene data. The kernels also STORE to global memory (the path pool), so the compiler
 // cannot prove that a plain load with a uniform address is never clobbered and issues a vector load for it: every lane

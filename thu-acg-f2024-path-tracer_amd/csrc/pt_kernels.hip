@@ -913,7 +913,7 @@ struct NoPrefetch {
 // younger load is waited for — hence the phase discipline (tex values fetched up front, pt_dev_bsdf.h fetch_tex).
 template <class Prefetch>
 PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane, const SlotIn& in,
-                       uint32_t& shard, unsigned long long& n_done, unsigned long long& n_died, Prefetch&& prefetch) {
+                       uint32_t& shard, uint32_t& n_done, uint32_t& n_died, Prefetch&& prefetch) {
     PT_STAMP(1);
     uint32_t bounce = in.bounce;
     const bool alive = bounce != SLOT_DEAD;
@@ -1129,7 +1129,7 @@ constexpr int SORT_WINDOW = 2048;   // slots sorted together by k_shade<true, *>
 // waves of the block (work stealing), and every slot's records are moved whole by its own lane.
 template <bool SORT, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
-    unsigned long long n_done = 0, n_died = 0;
+    uint32_t n_done = 0, n_died = 0;   // per thread and launch: far below 2^32 (64-bit counters here were the kernel's only spills)
     const int lane = (int)(threadIdx.x & 63u);
 #ifdef PT_STAMPS
     for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * PROF_COLS; i += BLOCK) (&g_prof[0][0])[i] = 0ull;
@@ -1302,8 +1302,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
 #endif
         }
     }
-    if (n_done) atomicAdd(&cnt->samples, n_done);
-    if (n_died) atomicSub(&cnt->alive, n_died);
+    if (n_done) atomicAdd(&cnt->samples, (unsigned long long)n_done);
+    if (n_died) atomicSub(&cnt->alive, (unsigned long long)n_died);
 #ifdef PT_STAMPS
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * PROF_COLS; i += BLOCK)
