@@ -35,25 +35,32 @@ template <class T> PT_DEV void stnt(T* p, T v) { __builtin_nontemporal_store(v, 
 // ---- path records (pt_types.h RayRec / PathRec): one lane moves one whole record, 16 B per access ----
 typedef double d2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+// PoolD::compact (scenes in which nothing moves, CamD::motionless: Ray::time reaches no result): the ray record's time slot
+// carries (pixel, bounce number) instead, so a path at bounce 0 — throughput (1,1,1) by definition — has no PathRec worth
+// writing: a regenerated camera ray costs one 64-byte record, not 96 bytes.
 PT_DEV RayD load_ray(const PoolD& pool, uint32_t s) {
     const d2v* p = reinterpret_cast<const d2v*>(&pool.ray[s]);
     const d2v a = p[0], b = p[1], c = p[2], d = p[3];
-    return RayD{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, d.x};
+    return RayD{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, pool.compact ? 0.0 : d.x};
 }
-PT_DEV RayD load_ray(const PoolD& pool, uint32_t s, uint32_t& sample, uint32_t& draw) {
+// `tail`: the record's words 12, 13 — the bits of Ray::time, or (pixel, bounce) in compact mode
+PT_DEV RayD load_ray(const PoolD& pool, uint32_t s, uint32_t& sample, uint32_t& draw, uint32_t (&tail)[2]) {
     const d2v* p = reinterpret_cast<const d2v*>(&pool.ray[s]);
     const d2v a = p[0], b = p[1], c = p[2];
     const u4v d = *reinterpret_cast<const u4v*>(p + 3);
     sample = d.z;
     draw = d.w;
-    return RayD{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, __hiloint2double((int)d.y, (int)d.x)};
+    tail[0] = d.x;
+    tail[1] = d.y;
+    return RayD{V3{a.x, a.y, b.x}, V3{b.y, c.x, c.y}, pool.compact ? 0.0 : __hiloint2double((int)d.y, (int)d.x)};
 }
-PT_DEV void store_ray(const PoolD& pool, uint32_t s, const RayD& r, uint32_t sample, uint32_t draw) {
+PT_DEV void store_ray(const PoolD& pool, uint32_t s, const RayD& r, uint32_t sample, uint32_t draw, uint32_t pixel, uint32_t bounce) {
     d2v* p = reinterpret_cast<d2v*>(&pool.ray[s]);
     p[0] = d2v{r.o.x, r.o.y};
     p[1] = d2v{r.o.z, r.d.x};
     p[2] = d2v{r.d.y, r.d.z};
-    *reinterpret_cast<u4v*>(p + 3) = u4v{(uint32_t)__double2loint(r.time), (uint32_t)__double2hiint(r.time), sample, draw};
+    *reinterpret_cast<u4v*>(p + 3) = pool.compact ? u4v{pixel, bounce, sample, draw}
+                                                  : u4v{(uint32_t)__double2loint(r.time), (uint32_t)__double2hiint(r.time), sample, draw};
 }
 PT_DEV V3 load_path(const PoolD& pool, uint32_t s, uint32_t& pixel, uint32_t& bounce) {
     const d2v* p = reinterpret_cast<const d2v*>(&pool.path[s]);
@@ -300,15 +307,15 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
             pool.rx[s] = 0.0; pool.ry[s] = 0.0; pool.rz[s] = 0.0;
         }
         pool.hit_prim[s] = (CLASS_DEAD << HIT_CLASS_SHIFT) | HIT_ID_MASK;   // overwritten by the first K2 launch
-        store_path(pool, s, V3{1.0, 1.0, 1.0}, pixel, 0u);
+        if (!pool.compact) store_path(pool, s, V3{1.0, 1.0, 1.0}, pixel, 0u);
         if (!has_work || idle) {
             pool.bounce[s] = idle ? SLOT_IDLE : SLOT_DEAD;
-            store_ray(pool, s, RayD{}, sample, 0u);
+            store_ray(pool, s, RayD{}, sample, 0u, pixel, 0u);
             continue;
         }
         Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, 0u};
         RayD r = generate_ray(cam, row, col, rng);
-        store_ray(pool, s, r, sample, rng.draw);
+        store_ray(pool, s, r, sample, rng.draw, pixel, 0u);
         pool.bounce[s] = 0;
     }
 }
@@ -856,8 +863,17 @@ PT_DEV SlotIn load_slot_global(const PoolD& pool, uint32_t s, bool enable, const
     in.hw = hw_known ? *hw_known : pool.hit_prim[s];
     in.bounce = enable ? state_of_class(in.hw) : SLOT_DEAD;
     if (in.bounce < SLOT_IDLE) {
-        in.thr = load_path(pool, s, in.pixel, in.bounce);
-        in.ray = load_ray(pool, s, in.sample, in.draw);
+        uint32_t tail[2];
+        in.ray = load_ray(pool, s, in.sample, in.draw, tail);
+        if (pool.compact) {
+            in.pixel = tail[0];
+            in.bounce = tail[1];
+            in.thr = V3{1.0, 1.0, 1.0};
+            uint32_t p2, b2;
+            if (in.bounce != 0u) in.thr = load_path(pool, s, p2, b2);      // a path at bounce 0 has no PathRec
+        } else {
+            in.thr = load_path(pool, s, in.pixel, in.bounce);
+        }
     }
     return in;
 }
@@ -880,18 +896,24 @@ PT_DEV void stage_fetch(const PoolD& pool, uint32_t s, uint4 (*stage)[64]) {
     __builtin_amdgcn_global_load_lds((glb_ptr)(p + 16), (lds_ptr)&stage[5][0], 16, 0, 0);
 }
 // the staged records of this lane (after the issuing wave's s_waitcnt vmcnt(0): nothing else orders an LDS read behind an LDS-DMA)
-PT_DEV SlotIn load_slot_stage(const uint4 (*stage)[64], int lane, bool enable, uint32_t hw) {
+PT_DEV SlotIn load_slot_stage(const PoolD& pool, const uint4 (*stage)[64], int lane, bool enable, uint32_t hw) {
     SlotIn in{};
     in.hw = hw;
     const uint4 a = stage[0][lane], b = stage[1][lane], c = stage[2][lane], d = stage[3][lane], e = stage[4][lane], f = stage[5][lane];
     auto f64 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
-    in.ray = RayD{V3{f64(a.x, a.y), f64(a.z, a.w), f64(b.x, b.y)}, V3{f64(b.z, b.w), f64(c.x, c.y), f64(c.z, c.w)}, f64(d.x, d.y)};
+    in.ray = RayD{V3{f64(a.x, a.y), f64(a.z, a.w), f64(b.x, b.y)}, V3{f64(b.z, b.w), f64(c.x, c.y), f64(c.z, c.w)}, pool.compact ? 0.0 : f64(d.x, d.y)};
     in.sample = d.z;
     in.draw = d.w;
     in.thr = V3{f64(e.x, e.y), f64(e.z, e.w), f64(f.x, f.y)};
     in.pixel = f.z;
     const uint32_t state = state_of_class(hw);
-    in.bounce = !enable ? SLOT_DEAD : state < SLOT_IDLE ? f.w : state;   // the bounce number rides in the PathRec
+    uint32_t bounce = f.w;                                               // the bounce number rides in the PathRec ...
+    if (pool.compact) {                                                  // ... or, with the pixel, in the ray record's time slot
+        in.pixel = d.x;
+        bounce = d.y;
+        if (bounce == 0u) in.thr = V3{1.0, 1.0, 1.0};                    // (the staged PathRec of a fresh path is stale)
+    }
+    in.bounce = !enable ? SLOT_DEAD : state < SLOT_IDLE ? bounce : state;
     return in;
 }
 struct NoPrefetch {
@@ -1092,8 +1114,8 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         const uint32_t state_new = bounce < SLOT_IDLE ? 0u : bounce, state_old = was_idle ? SLOT_IDLE : 0u;
         if (state_new != state_old) pool.bounce[s] = state_new;       // the state array changes only with the slot's state
         if (bounce < SLOT_IDLE) {
-            store_ray(pool, s, ray, sample, rng.draw);
-            store_path(pool, s, thr, pixel, bounce);
+            store_ray(pool, s, ray, sample, rng.draw, pixel, bounce);
+            if (!pool.compact || bounce != 0u) store_path(pool, s, thr, pixel, bounce);
             if (!pool.dynamic) { pool.rx[s] = rad.x; pool.ry[s] = rad.y; pool.rz[s] = rad.z; }
         }
     }
@@ -1259,7 +1281,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 const uint32_t hw = s_hw[s - wbase];
                 if (staged) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed (and this wave's older stores with it)
-                    in = load_slot_stage(stage, lane, enable, hw);
+                    in = load_slot_stage(pool, stage, lane, enable, hw);
                 } else {
                     in = load_slot_global(pool, s, enable, &hw);
                 }

@@ -272,6 +272,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     pool.spp_end = spp_end;
     pool.dynamic = dynamic ? 1u : 0u;
     pool.defer_regen = (dynamic && !exp_env("PT_NO_DEFER_REGEN")) ? 1u : 0u;
+    pool.compact = (dc.motionless && !exp_env("PT_NO_COMPACT_RECORDS")) ? 1u : 0u;
     pool.total_work = total_work;
     pool.width = dc.width;
     pool.height = dc.height;

@@ -210,7 +210,7 @@ struct PoolD {
     uint32_t n_slots, n_pixels, k;                // k = slots per pixel (static mode)
     uint32_t spp_begin, spp_end;
     uint32_t dynamic, n_alloc;                    // n_alloc: slots rounded up to a multiple of 64
-    uint32_t defer_regen, pad_;                   // dynamic mode: a path that ends ON A SURFACE (roulette, sampler, depth) parks its slot
+    uint32_t defer_regen, compact;                   // dynamic mode: a path that ends ON A SURFACE (roulette, sampler, depth) parks its slot
                                                   // as SLOT_IDLE; it is refilled next iteration among the idle slots (k_shade)
     uint32_t width, height, tiles_x, n_tile_pixels;   // dynamic mode: 8x8 tiling, n_tile_pixels = tiles_x*tiles_y*64
 };
