@@ -52,7 +52,8 @@ def m(k, c):
 
 cal = {}
 if m("k_init", "WRITE_SIZE"):
-    cal["write_factor"] = slots * (64 + 32 + 4 + 4) / (out["k_init"]["WRITE_SIZE"]["first"] * 1024)   # k_init writes RayRec + PathRec + hit_prim + bounce
+    # k_init writes RayRec + hit_prim + state per slot (and a PathRec only without compact records: scenes with moving spheres)
+    cal["write_factor"] = slots * (64 + 4 + 4) / (out["k_init"]["WRITE_SIZE"]["first"] * 1024)
 if m("k_extend", "FETCH_SIZE"):
     cal["fetch_factor_first_extend"] = slots * (64 + 4) / (out["k_extend"]["FETCH_SIZE"]["first"] * 1024)   # first K2 launch: every slot alive
 out["calibration"] = cal
