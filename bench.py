@@ -14,6 +14,11 @@ what the value is computed from.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--spp 4000] [--width 1920] [--scene 6]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started plainly with --gpus N > 1 (no RANK in the environment) the script launches its N ranks ITSELF: the parent touches no
+GPU, starts N fresh child processes of this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and a launch token set,
+relays rank 0's JSON line and exits with the worst child's code. Under a launcher (torchrun) it is one rank, as before.
+`n_gpus` in the JSON is the communicator's size (pt_comm_world), never the flag.
+
 Prints ONE JSON line on rank 0. `roofline` is measured live with HIP events on the launch stream
 (pt_render's profile mode); `cpu_baseline` times the CPU oracle (kind "port": the faithful f64
 restatement with the platform libm; the Rust reference itself cannot be built here) on a bounded
@@ -23,8 +28,11 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import uuid
 
 import numpy as np
 
@@ -55,7 +63,60 @@ def parse():
     ap.add_argument("--slots-per-pixel", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="plumbing check without a GPU: every rank only runs the file rendezvous of pt_comm_create (pt_bootstrap_exchange) and rank 0 reports")
     return ap.parse_args()
+
+
+def rendezvous_path():
+    """The file through which rank 0 hands the RCCL unique id to the other ranks of THIS launch: named by a token every rank
+    of the launch shares and no other launch has — PT_AMD_LAUNCH_TOKEN (self-spawn: a fresh uuid), else torchrun's run id +
+    MASTER_PORT + the launcher's pid (the ranks of one torchrun are children of one agent process)."""
+    token = os.environ.get("PT_AMD_LAUNCH_TOKEN")
+    if not token:
+        token = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pt_amd_rccl_id_{token}")
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start the N ranks as fresh child processes. Nothing in this (parent) process has
+    touched the GPU or loaded the library."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    token = f"{uuid.uuid4().hex}_{os.getpid()}"
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PT_AMD_LAUNCH_TOKEN=token,
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    stale = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pt_amd_rccl_id_{token}")
+    for f in (stale, stale + ".tmp"):             # (a fresh uuid: nothing can be there; removed before any child exists all the same)
+        if os.path.exists(f):
+            os.unlink(f)
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=60 if codes[0] == 0 else 5))
+        except subprocess.TimeoutExpired:
+            p.kill()                                  # our own child, by handle
+            codes.append(p.wait())
+    for f in (stale, stale + ".tmp"):
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    worst = max((abs(c) for c in codes), default=0)
+    if worst == 0 and not lines:
+        worst = 1
+    sys.exit(worst)
 
 
 def cpu_baseline(scene_id, width, seconds, images):
@@ -112,20 +173,26 @@ def frame_check(pt, ctx, args, acc, height):
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)                        # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC between the ranks' processes (RCCL)
 
     pt = importlib.import_module("thu-acg-f2024-path-tracer_amd")
+    id_path = rendezvous_path()
+    if args.rendezvous_only:                           # host-side plumbing only (tests/test_distributed_cpu.py): no GPU, no render
+        token = bytes(range(128)) if rank == 0 else bytes(128)
+        got = pt.bootstrap_exchange(id_path, rank, token, 60.0) if world > 1 else token
+        ok = got == bytes(range(128))
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rank0_pid": os.getpid(), "launcher": "self" if os.environ.get("PT_AMD_LAUNCH_TOKEN") else "external",
+                              "id_path": id_path}), flush=True)
+        sys.exit(0 if ok else 1)
     ctx = pt.Context(local_rank)                       # fails loudly without a GPU
-    # rendezvous file of THIS launch: MASTER_PORT + the launcher's pid (the same for every rank of one torchrun)
-    id_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pt_amd_rccl_id_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
-    if rank == 0 and world > 1 and os.path.exists(id_path):
-        os.unlink(id_path)
     comm = pt.Comm(ctx, rank, world, id_path if world > 1 else None)
+    world = comm.world                                 # the communicator's word, not the flag's or the environment's
     scene = pt.Scene(ctx)
     t0 = time.time()
     cam = scene.build_scene(args.scene, args.width, args.spp)
@@ -133,8 +200,10 @@ def main():
     height = pt.image_height(cam)
     n_pix = args.width * height
 
+    frame = np.zeros((height, args.width, 3), dtype=np.float64) if rank == 0 else None    # one landing buffer, overwritten by every frame
+
     def step(profile):
-        return scene.render_multi(cam, args.seed, args.spp, comm, slots_per_pixel=args.slots_per_pixel, profile=profile)
+        return scene.render_multi(cam, args.seed, args.spp, comm, accum=frame, slots_per_pixel=args.slots_per_pixel, profile=profile, overwrite=True)
 
     for _ in range(args.warmup):
         step(False)
@@ -151,7 +220,7 @@ def main():
     total_segments, total_samples = comm.allreduce([sum(s["segments"] for s in stats), sum(s["samples"] for s in stats)], "sum")
     if rank == 0 and world > 1:
         try:
-            os.unlink(id_path)
+            os.unlink(id_path)                         # every rank is past ncclCommInitRank
         except OSError:
             pass
 
@@ -162,7 +231,7 @@ def main():
         ms_ext = sum(s["ms_extend"] for s in stats); ms_sh = sum(s["ms_shade"] for s in stats)
         n_ext = sum(s["launches_extend"] for s in stats); n_sh = sum(s["launches_shade"] for s in stats)
         my_seg = sum(s["segments"] for s in stats); my_smp = sum(s["samples"] for s in stats)
-        ext_name = {0: "k_extend2", 1: "k_extend", 2: "k_extend_fetch"}.get(stats[0]["extend_variant"], "k_extend")
+        ext_name = {0: "k_extend2", 1: "k_extend"}.get(stats[0]["extend_variant"], "k_extend")
         sh_name = f"k_shade<{'true' if stats[0]['shade_variant'] >= 10 else 'false'}, {stats[0]['shade_variant'] % 10}>"
         if ms_ext >= ms_sh:
             kname, kms, kn = ext_name, ms_ext, n_ext
@@ -184,7 +253,9 @@ def main():
                 traffic_source = f"profiles/pmc_latest.json ({pmc.get('source', 'earlier rocprofv3 --pmc passes of this command')}), not measured in this run"
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        model = (f"algorithmic bytes = SURVEY §8(d) yardstick: K3 {B_SHADE_PER_SEGMENT} B/segment (92 B record in + 4 B hit word + 92 B record out) + {B_FB_PER_SAMPLE} B/sample "
+                 f"(f64 accumulator), K2 {B_EXTEND_PER_SEGMENT} B/segment (56 B ray in + 4 B out); the code's compact records move less than the yardstick assumes (DESIGN.md §6)")
+        roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "model": model,
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(kn),
                     "algorithmic_bytes_per_launch": round(bytes_total / max(kn, 1), 1),

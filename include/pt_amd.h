@@ -43,7 +43,7 @@ typedef struct pt_render_opts {
                                    reference's exact per-pixel sample order */
     uint32_t accum_on_device;   /* accum points to device memory (e.g. a torch tensor) */
     uint32_t profile;           /* time every kernel launch with HIP events */
-    uint32_t _pad;
+    uint32_t overwrite;         /* 0: the frame's sums are ADDED to accum (sample ranges accumulate); 1: accum is overwritten */
     void* stream;               /* hipStream_t to launch on; NULL = the context's own stream */
 } pt_render_opts;
 
@@ -154,8 +154,9 @@ int pt_comm_barrier(pt_comm*);        /* all ranks have arrived and every device
 int pt_comm_allreduce_f64(pt_comm*, double* host_values, uint32_t n /* <= 64 */, int op /* 0 sum, 1 max */);
 int pt_bootstrap_exchange(const char* path, int rank, void* bytes, uint32_t n, double timeout_s);   /* the file rendezvous itself (host only) */
 /* Camera::render on all ranks of the communicator: samples [0, spp_total) split by pt_shard_range, rendered into a
- * device accumulator, reduced onto rank 0 and ADDED there to accum_root (host, W*H*3 sums; ignored on other ranks).
- * stats are this rank's. */
+ * device accumulator, reduced onto rank 0 and ADDED there to accum_root (host, W*H*3 sums; ignored on other ranks;
+ * opts->overwrite: stored instead of added). stats are this rank's. A failure on any rank is agreed on before the
+ * reduce is posted: every rank returns -1 and no rank waits; a failure inside a collective aborts the communicator. */
 int pt_render_multi(pt_scene*, const pt_camera*, uint64_t seed, uint32_t spp_total, pt_comm*, double* accum_root,
                     const pt_render_opts* opts, pt_render_stats* stats);
 

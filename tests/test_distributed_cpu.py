@@ -6,8 +6,10 @@ from rank 0 to the others). The renderer behind the shard is the CPU oracle and 
 accumulators is a gloo reduce — on GPUs those two are pt_render and ncclReduce inside pt_render_multi (csrc/pt_comm.cpp;
 its 1-rank form is tested on the GPU in test_gpu_parity.py)."""
 import importlib
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -81,3 +83,37 @@ def test_two_rank_render_equals_single_process(orc, tmp_path):
     # set, only the summation order differs
     np.testing.assert_allclose(got["accum"], ref, rtol=1e-13, atol=1e-13)
     s.close()
+
+
+def _clean_env(tmp_path):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "PT_AMD_LAUNCH_TOKEN")}
+    env["TMPDIR"] = str(tmp_path)
+    return env
+
+
+def test_bench_self_spawn_starts_its_ranks_and_relays_one_json_line(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: the parent must start two fresh rank processes (RANK / WORLD_SIZE /
+    launch token set), relay exactly rank 0's JSON line and leave no rendezvous file behind. --rendezvous-only keeps the
+    ranks to the host-side plumbing (pt_bootstrap_exchange through the C ABI): there is no GPU here; what runs behind the
+    rendezvous on GPUs is covered by test_two_rank_render_equals_single_process (gloo / oracle standing in)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=_clean_env(tmp_path),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launcher"] == "self" and d["rendezvous_only"] is True
+    assert d["rank0_pid"] != os.getpid()
+    assert os.path.dirname(d["id_path"]) == str(tmp_path)
+    assert [f for f in os.listdir(tmp_path) if f.startswith("pt_amd_rccl_id_")] == []
+
+
+def test_bench_under_a_launcher_is_one_rank_and_does_not_spawn(tmp_path):
+    """With RANK in the environment (torchrun's contract) bench.py is ONE rank of the launch: it never starts children, and its
+    rendezvous file is named by the launcher's run id, port and pid."""
+    env = dict(_clean_env(tmp_path), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29411", TORCHELASTIC_RUN_ID="job7")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip())
+    assert d["n_gpus"] == 1 and d["launcher"] == "external"          # the communicator's size, not the flag
+    assert os.path.basename(d["id_path"]) == f"pt_amd_rccl_id_job7_29411_{os.getpid()}"

@@ -55,7 +55,7 @@ class RenderOpts(C.Structure):
         ("slots_per_pixel", C.c_uint32),
         ("accum_on_device", C.c_uint32),
         ("profile", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("overwrite", C.c_uint32),
         ("stream", C.c_void_p),
     ]
 
@@ -251,7 +251,8 @@ class Comm:
     def __init__(self, ctx: Context, rank: int, world: int, id_path: Optional[str] = None, timeout_s: float = 120.0):
         h = C.c_void_p()
         _check(lib.pt_comm_create(ctx.handle, rank, world, None if id_path is None else id_path.encode(), timeout_s, C.byref(h)), "pt_comm_create")
-        self.handle, self.ctx, self.rank, self.world = h, ctx, rank, world
+        self.handle, self.ctx = h, ctx
+        self.rank, self.world = int(lib.pt_comm_rank(h)), int(lib.pt_comm_world(h))     # what the communicator says, not what was asked for
 
     def close(self):
         if self.handle:
@@ -353,12 +354,12 @@ class Scene:
         return cam
 
     def render(self, cam: Camera, seed: int, spp_begin: int, spp_end: int, accum=None, slots_per_pixel: int = 0,
-               profile: bool = False, device_ptr: Optional[int] = None, stream: Optional[int] = None):
+               profile: bool = False, device_ptr: Optional[int] = None, stream: Optional[int] = None, overwrite: bool = False):
         """Camera::render (camera.rs:79) without gamma/quantise: returns (accum, stats) where
-        accum[(y, x, c)] += sum over samples [spp_begin, spp_end) of trace(y, x).
+        accum[(y, x, c)] += sum over samples [spp_begin, spp_end) of trace(y, x) (``overwrite``: = instead of +=).
         ``device_ptr``: write into device memory instead (e.g. ``tensor.data_ptr()``)."""
         h = image_height(cam)
-        opts = RenderOpts(slots_per_pixel, 1 if device_ptr is not None else 0, 1 if profile else 0, 0, stream)
+        opts = RenderOpts(slots_per_pixel, 1 if device_ptr is not None else 0, 1 if profile else 0, 1 if overwrite else 0, stream)
         stats = RenderStats()
         if device_ptr is not None:
             ptr = C.c_void_p(device_ptr)
@@ -370,11 +371,13 @@ class Scene:
         _check(lib.pt_render(self.handle, C.byref(cam), seed, spp_begin, spp_end, ptr, C.byref(opts), C.byref(stats)), "pt_render")
         return accum, stats
 
-    def render_multi(self, cam: Camera, seed: int, spp_total: int, comm: Comm, accum=None, slots_per_pixel: int = 0, profile: bool = False):
+    def render_multi(self, cam: Camera, seed: int, spp_total: int, comm: Comm, accum=None, slots_per_pixel: int = 0, profile: bool = False,
+                     overwrite: bool = False):
         """Camera::render over all ranks of `comm` (pt_render_multi): spp sharding + one RCCL reduce onto rank 0.
-        Returns (accum on rank 0 / None elsewhere, this rank's stats)."""
+        Returns (accum on rank 0 / None elsewhere, this rank's stats). ``overwrite``: the frame replaces ``accum``'s content
+        instead of being added to it (a host that renders frame after frame into one buffer)."""
         h = image_height(cam)
-        opts = RenderOpts(slots_per_pixel, 0, 1 if profile else 0, 0, None)
+        opts = RenderOpts(slots_per_pixel, 0, 1 if profile else 0, 1 if overwrite else 0, None)
         stats = RenderStats()
         ptr = None
         if comm.rank == 0:

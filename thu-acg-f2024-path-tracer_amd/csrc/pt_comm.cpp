@@ -30,6 +30,9 @@ struct pt_comm {
     double* d_scratch = nullptr;     // small device buffer for host-value collectives
     double* d_accum = nullptr;       // frame accumulator of pt_render_multi (grown on demand)
     size_t accum_bytes = 0;
+    double* h_stage = nullptr;       // rank 0: pinned landing buffer of the reduced frame (grown on demand)
+    size_t stage_bytes = 0;
+    bool aborted = false;            // ncclCommAbort was called after a local failure: every later collective fails at once
 };
 
 // RCCL prints a version banner ("RCCL version : ...", five lines) on STDOUT when the first communicator of a process is
@@ -103,10 +106,31 @@ extern "C" int pt_comm_create(pt_ctx* ctx, int rank, int world, const char* id_p
     if (world > 1 && (!id_path || !*id_path)) return set_error("pt_comm_create: a rendezvous path is needed for world > 1");
     if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return -1;
     StdoutToStderr quiet;   // until this function returns
-    ncclUniqueId id;
-    memset(&id, 0, sizeof id);
-    if (rank == 0 && !nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId")) return -1;
-    if (world > 1 && pt_bootstrap_exchange(id_path, rank, &id, (uint32_t)sizeof id, timeout_s > 0 ? timeout_s : 120.0) != 0) return -1;
+    // what travels through the file: a header naming this library and the launch's world size, then the id. A reader that finds
+    // anything else there (a file some other program or an earlier launch of another size left under the same name) keeps polling
+    // until rank 0 has replaced it (rename is atomic) or the timeout strikes.
+    struct IdFile {
+        char magic[8];
+        uint32_t world, reserved;
+        ncclUniqueId id;
+    } msg;
+    static const char MAGIC[8] = {'P', 'T', 'A', 'M', 'D', 'I', 'D', '1'};
+    memset(&msg, 0, sizeof msg);
+    memcpy(msg.magic, MAGIC, 8);
+    msg.world = (uint32_t)world;
+    if (rank == 0 && !nccl_ok(ncclGetUniqueId(&msg.id), "ncclGetUniqueId")) return -1;
+    if (world > 1) {
+        const double limit = timeout_s > 0 ? timeout_s : 120.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const double left = limit - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (pt_bootstrap_exchange(id_path, rank, &msg, (uint32_t)sizeof msg, left > 0.05 ? left : 0.05) != 0) return -1;
+            if (rank == 0 || (memcmp(msg.magic, MAGIC, 8) == 0 && msg.world == (uint32_t)world)) break;
+            if (left <= 0.05) return set_error(std::string("pt_comm_create: ") + id_path + " holds no rendezvous record of this launch (stale file?)");
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    const ncclUniqueId id = msg.id;
     pt_comm* c = new pt_comm();
     c->ctx = ctx;
     c->rank = rank;
@@ -125,6 +149,7 @@ extern "C" void pt_comm_destroy(pt_comm* c) {
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->d_accum) (void)hipFree(c->d_accum);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     delete c;
@@ -132,15 +157,33 @@ extern "C" void pt_comm_destroy(pt_comm* c) {
 extern "C" int pt_comm_rank(pt_comm* c) { return c ? c->rank : -1; }
 extern "C" int pt_comm_world(pt_comm* c) { return c ? c->world : -1; }
 
+// A rank that fails locally between two collectives must not leave its peers blocked in the next one for ever (RCCL has no
+// timeout): the communicator is aborted — the peers' pending and future collectives return an error — and this handle refuses
+// further use.
+static int abort_comm(pt_comm* c, const std::string& why) {
+    if (c->comm && !c->aborted) (void)ncclCommAbort(c->comm);
+    c->comm = nullptr;
+    c->aborted = true;
+    return set_error(why + " (communicator aborted: the other ranks' collectives fail instead of waiting)");
+}
+static bool comm_usable(pt_comm* c, const char* who) {
+    if (c && !c->aborted && c->comm) return true;
+    set_error(std::string(who) + (c && c->aborted ? ": the communicator was aborted after an earlier failure" : ": null communicator"));
+    return false;
+}
+
 // all-reduce of up to 64 host doubles (op: 0 sum, 1 max) — the bench's barrier, max-over-ranks clock and counters
 extern "C" int pt_comm_allreduce_f64(pt_comm* c, double* values, uint32_t n, int op) {
-    if (!c || !values || n == 0 || n > 64) return set_error("pt_comm_allreduce_f64: bad arguments (1..64 values)");
-    if (!hip_ok(hipSetDevice(c->ctx->device), "hipSetDevice")) return -1;
+    if (!comm_usable(c, "pt_comm_allreduce_f64")) return -1;
+    if (!values || n == 0 || n > 64) return set_error("pt_comm_allreduce_f64: bad arguments (1..64 values)");
     hipStream_t st = c->ctx->stream;
-    if (!hip_ok(hipMemcpyAsync(c->d_scratch, values, n * sizeof(double), hipMemcpyHostToDevice, st), "hipMemcpy(allreduce in)")) return -1;
-    if (!nccl_ok(ncclAllReduce(c->d_scratch, c->d_scratch, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, st), "ncclAllReduce")) return -1;
-    if (!hip_ok(hipMemcpyAsync(values, c->d_scratch, n * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpy(allreduce out)")) return -1;
-    return hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(allreduce)") ? 0 : -1;
+    const bool ok = hip_ok(hipSetDevice(c->ctx->device), "hipSetDevice") &&
+                    hip_ok(hipMemcpyAsync(c->d_scratch, values, n * sizeof(double), hipMemcpyHostToDevice, st), "hipMemcpy(allreduce in)") &&
+                    nccl_ok(ncclAllReduce(c->d_scratch, c->d_scratch, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, st), "ncclAllReduce") &&
+                    hip_ok(hipMemcpyAsync(values, c->d_scratch, n * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpy(allreduce out)") &&
+                    hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(allreduce)");
+    if (!ok && c->world > 1) return abort_comm(c, std::string("pt_comm_allreduce_f64: ") + pt::last_error());
+    return ok ? 0 : -1;
 }
 extern "C" int pt_comm_barrier(pt_comm* c) {
     double one = 1.0;
@@ -150,38 +193,67 @@ extern "C" int pt_comm_barrier(pt_comm* c) {
 
 extern "C" int pt_render_multi(pt_scene* s, const pt_camera* cam, uint64_t seed, uint32_t spp_total, pt_comm* c, double* accum_root,
                                const pt_render_opts* opts_in, pt_render_stats* stats) {
-    if (!s || !cam || !c) return set_error("pt_render_multi: bad arguments");
-    if (pt_scene_ctx(s) != c->ctx) return set_error("pt_render_multi: the scene and the communicator belong to different contexts");
-    if (c->rank == 0 && !accum_root) return set_error("pt_render_multi: rank 0 needs the output accumulator");
-    if (!hip_ok(hipSetDevice(c->ctx->device), "hipSetDevice")) return -1;
-    double v[18];
-    uint32_t height = 0;
-    if (pt_camera_init(cam, v, &height) != 0) return -1;
-    const size_t n = (size_t)cam->image_width * height * 3, bytes = n * sizeof(double);
-    if (bytes > c->accum_bytes) {
-        if (c->d_accum) (void)hipFree(c->d_accum);
-        c->d_accum = nullptr;
-        c->accum_bytes = 0;
-        if (!hip_ok(hipMalloc((void**)&c->d_accum, bytes), "hipMalloc(frame accumulator)")) return -1;
-        c->accum_bytes = bytes;
-    }
+    if (!comm_usable(c, "pt_render_multi")) return -1;
+    // Everything that can fail on ONE rank only runs inside `local`; the ranks then agree on the outcome (a one-word all-reduce)
+    // BEFORE the frame's reduce is posted, so that a rank whose render failed does not leave the others waiting in ncclReduce.
+    size_t n = 0, bytes = 0;
     hipStream_t st = c->ctx->stream;
-    if (!hip_ok(hipMemsetAsync(c->d_accum, 0, bytes, st), "hipMemset(frame accumulator)")) return -1;
     pt_render_opts opts;
     memset(&opts, 0, sizeof opts);
     if (opts_in) opts = *opts_in;
-    opts.accum_on_device = 1;
-    opts.stream = (void*)st;
-    uint32_t lo, hi;
-    pt_shard_range(spp_total, c->rank, c->world, &lo, &hi);
-    if (pt_render(s, cam, seed, lo, hi, c->d_accum, &opts, stats) != 0) return -1;
-    // the frame's single collective: sum of the per-rank sample SUMS, in place on the root, on the render stream
-    if (c->world > 1 && !nccl_ok(ncclReduce(c->d_accum, c->d_accum, n, ncclDouble, ncclSum, 0, c->comm, st), "ncclReduce")) return -1;
+    const bool overwrite = opts.overwrite != 0;
+    auto local = [&]() -> int {
+        if (!s || !cam) return set_error("pt_render_multi: bad arguments");
+        if (pt_scene_ctx(s) != c->ctx) return set_error("pt_render_multi: the scene and the communicator belong to different contexts");
+        if (c->rank == 0 && !accum_root) return set_error("pt_render_multi: rank 0 needs the output accumulator");
+        if (!hip_ok(hipSetDevice(c->ctx->device), "hipSetDevice")) return -1;
+        double v[18];
+        uint32_t height = 0;
+        if (pt_camera_init(cam, v, &height) != 0) return -1;
+        n = (size_t)cam->image_width * height * 3;
+        bytes = n * sizeof(double);
+        if (bytes > c->accum_bytes) {
+            if (c->d_accum) (void)hipFree(c->d_accum);
+            c->d_accum = nullptr;
+            c->accum_bytes = 0;
+            if (!hip_ok(hipMalloc((void**)&c->d_accum, bytes), "hipMalloc(frame accumulator)")) return -1;
+            c->accum_bytes = bytes;
+        }
+        if (c->rank == 0 && bytes > c->stage_bytes) {
+            if (c->h_stage) (void)hipHostFree(c->h_stage);
+            c->h_stage = nullptr;
+            c->stage_bytes = 0;
+            if (!hip_ok(hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault), "hipHostMalloc(frame staging)")) return -1;
+            c->stage_bytes = bytes;
+        }
+        if (!hip_ok(hipMemsetAsync(c->d_accum, 0, bytes, st), "hipMemset(frame accumulator)")) return -1;
+        pt_render_opts o = opts;
+        o.accum_on_device = 1;
+        o.overwrite = 0;                 // the device accumulator was just cleared
+        o.stream = (void*)st;
+        uint32_t lo, hi;
+        pt_shard_range(spp_total, c->rank, c->world, &lo, &hi);
+        return pt_render(s, cam, seed, lo, hi, c->d_accum, &o, stats);
+    };
+    const int rc = local();
+    if (c->world > 1) {
+        const std::string own = rc != 0 ? std::string(pt::last_error()) : std::string();
+        double failed = rc != 0 ? 1.0 : 0.0;
+        if (pt_comm_allreduce_f64(c, &failed, 1, 1) != 0) return -1;          // (aborts the communicator when it fails itself)
+        if (rc != 0) return set_error(own);
+        if (failed != 0.0) return set_error("pt_render_multi: the render failed on another rank; no frame was reduced");
+        // the frame's single collective: sum of the per-rank sample SUMS, in place on the root, on the render stream
+        if (!nccl_ok(ncclReduce(c->d_accum, c->d_accum, n, ncclDouble, ncclSum, 0, c->comm, st), "ncclReduce"))
+            return abort_comm(c, std::string("pt_render_multi: ") + pt::last_error());
+    } else if (rc != 0) {
+        return -1;
+    }
     if (c->rank == 0) {
-        std::vector<double> tmp(n);
-        if (!hip_ok(hipMemcpyAsync(tmp.data(), c->d_accum, bytes, hipMemcpyDeviceToHost, st), "hipMemcpy(frame)")) return -1;
+        // one DMA into the pinned landing buffer, then one pass over the caller's (pageable) frame
+        if (!hip_ok(hipMemcpyAsync(c->h_stage, c->d_accum, bytes, hipMemcpyDeviceToHost, st), "hipMemcpy(frame)")) return -1;
         if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(frame)")) return -1;
-        for (size_t i = 0; i < n; ++i) accum_root[i] += tmp[i];
+        if (overwrite) memcpy(accum_root, c->h_stage, bytes);
+        else for (size_t i = 0; i < n; ++i) accum_root[i] += c->h_stage[i];
     } else if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(reduce)")) {
         return -1;
     }

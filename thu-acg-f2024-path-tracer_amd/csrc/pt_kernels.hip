@@ -20,6 +20,7 @@
 namespace pt {
 
 constexpr int BLOCK = 256;
+constexpr int SORT_WINDOW_SLOTS = 2048;   // window size of k_extend2 and k_shade = the granule pt_render.cpp allocates the pool in
 // Resident blocks per CU the batch form of K2 is compiled for. Its register count sits right at the 128-register step
 // (4 waves per SIMD) and tipped over it with unrelated edits elsewhere in this file: measured on one build pair, scene 3's
 // K2 was 10 % faster at four blocks than at three, scene 5's 16 % — so the bound is stated instead of left to chance.
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(BLOCK, PAIRS ? 3 : PT_EXTEND_BATCH_BLOCKS) void k_e
     const PairLds pl{&s_pair_t[PAIRS ? wave * 64 : 0], &s_pair_id[PAIRS ? wave * 64 : 0], &s_pairs[PAIRS ? wave * PAIR_CAP : 0]};
     unsigned long long nseg = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
+    if (ldu(&cnt->alive) == 0ull) return;   // the frame is done: the launches the host had already queued behind its last poll cost a few microseconds each
     // n_alloc is a multiple of BLOCK: whole waves run every chunk (closest_hit_flat ballots)
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < pool.n_alloc; s += gridDim.x * BLOCK) {
         const uint32_t state = pool.bounce[s];
@@ -565,6 +567,8 @@ __shared__ unsigned long long g_prof[N_CLASSES + 1][PROF_COLS];
 constexpr int EXT_WINDOW = 2048;   // slots per block window
 constexpr uint32_t REFILL_MIN = 16;   // idle lanes that trigger a refill of the wave in phase B
 constexpr int EXT_CAND = 768;      // candidate list of a window (LDS); a fuller window walks the rest in phase A
+static_assert(EXT_WINDOW % BLOCK == 0 && EXT_WINDOW <= 65536, "k_extend2: s_cand_sl holds 16-bit slot offsets inside the window");
+static_assert(EXT_WINDOW == SORT_WINDOW_SLOTS, "the pool is allocated in whole windows of this size (pt_render.cpp rounds n_alloc to 2048)");
 
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
     const RayD r = ray_to_local_chain(sc, e.inst, wray);
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
     unsigned long long nseg = 0;
     const uint32_t n_windows = pool.n_alloc / EXT_WINDOW;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
+    if (ldu(&cnt->alive) == 0ull) return;   // (see k_extend)
 #ifdef PT_STAMPS
     if (threadIdx.x < 8) g_prof[CLASS_DEAD][threadIdx.x] = 0ull;
 #endif
@@ -830,13 +835,28 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
 // color += throughput * emitted (camera.rs:182,187). Static mode: into the sample's own sum, which reaches
 // the pixel when the sample ends (the reference's order of additions). Dynamic mode: straight into the
 // frame accumulator — exact zeros are skipped, NaN/inf are not (they poison the pixel like they do there).
+// pixel (row-major) -> its index inside a channel plane of the tiled frame accumulator (PoolD::accum)
+PT_DEV uint32_t tiled_index(const PoolD& pool, uint32_t pixel) {
+    uint32_t y = (uint32_t)((double)pixel * pool.inv_width);           // within 1 of pixel / width
+    int32_t x = (int32_t)(pixel - y * pool.width);
+    if (x < 0) { --y; x += (int32_t)pool.width; }
+    else if (x >= (int32_t)pool.width) { ++y; x -= (int32_t)pool.width; }
+    return ((y >> 3) * pool.tiles_x + ((uint32_t)x >> 3)) * 64u + ((y & 7u) << 3) + ((uint32_t)x & 7u);
+}
 PT_DEV void add_radiance(const PoolD& pool, uint32_t pixel, V3& rad, V3 c) {
     if (!pool.dynamic) {
         rad = rad + c;
     } else if (!(c.x == 0.0 && c.y == 0.0 && c.z == 0.0)) {
-        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], c.x);
-        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], c.y);
-        unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], c.z);
+        if (pool.accum_tiled) {
+            double* a = pool.accum + tiled_index(pool, pixel);
+            unsafeAtomicAdd(a, c.x);
+            unsafeAtomicAdd(a + pool.n_tile_pixels, c.y);
+            unsafeAtomicAdd(a + 2 * (size_t)pool.n_tile_pixels, c.z);
+        } else {
+            unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel], c.x);
+            unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 1], c.y);
+            unsafeAtomicAdd(&pool.accum[3 * (size_t)pixel + 2], c.z);
+        }
     }
 }
 
@@ -1138,7 +1158,13 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
 #endif
 }
 
-constexpr int SORT_WINDOW = 2048;   // slots sorted together by k_shade<true, *> (8 x 4-bit class keys per thread: do not enlarge without widening `keys`)
+constexpr int SORT_WINDOW = SORT_WINDOW_SLOTS;   // slots sorted together by k_shade<true, *>
+// Every thread packs the class keys of its SORT_WINDOW / BLOCK slots into ONE 32-bit word, 4 bits each. A 4096-slot window
+// (16 keys) overflowed that word in round 2 and the kernel hung: the bound is a compile error now, not a comment.
+static_assert((SORT_WINDOW / BLOCK) * 4 <= 32, "k_shade: the per-thread `keys` word holds at most eight 4-bit class keys — widen it before enlarging SORT_WINDOW");
+static_assert(N_CLASSES <= 16, "k_shade: a class key is 4 bits wide (and the class field of K2's result word is bits 28..31)");
+static_assert(SORT_WINDOW % BLOCK == 0 && SORT_WINDOW / 64 == 32, "k_shade: one half-wave scans the 32 group counts of a class");
+static_assert(SORT_WINDOW <= 65536, "k_shade: s_perm holds 16-bit slot offsets");
 #ifndef PT_K3_PREFETCH
 #define PT_K3_PREFETCH 1            // 0: every group's records straight from the pool (the round-1 form), for A/B
 #endif
@@ -1159,6 +1185,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
 #endif
     uint32_t shard = blockIdx.x % WORK_SHARDS;   // work-counter shard this wave draws from (wave-uniform; moves on when it runs dry)
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_extend = 0;
+    if (ldu(&cnt->alive) == 0ull) return;   // (see k_extend; a block subtracts its dead slots when it has run out of windows: zero means every window of the pool has been shaded)
     if (!SORT) {
         // n_alloc is a multiple of 256: whole waves run every chunk (wave ballots inside shade_slot)
         for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK) {
@@ -1349,6 +1376,16 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(PoolD pool, double* accum) {
     }
 }
 
+// dynamic mode with the tiled frame accumulator (PoolD::accum_tiled): accum[p*3+c] += plane c's sum of pixel p — once per render
+__global__ __launch_bounds__(BLOCK) void k_detile(PoolD pool, double* accum) {
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < pool.n_pixels; p += gridDim.x * BLOCK) {
+        const double* a = pool.accum + tiled_index(pool, p);
+        accum[3 * (size_t)p] += a[0];
+        accum[3 * (size_t)p + 1] += a[pool.n_tile_pixels];
+        accum[3 * (size_t)p + 2] += a[2 * (size_t)pool.n_tile_pixels];
+    }
+}
+
 // camera.rs:109-114,128-130: mean, sqrt gamma, clamp, truncate to u8
 __global__ __launch_bounds__(BLOCK) void k_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
@@ -1450,6 +1487,9 @@ void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, Counters
 }
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);
+}
+void launch_detile(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_detile, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);
 }
 void launch_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8, hipStream_t st) {
     hipLaunchKernelGGL(k_quantise, grid_for(n, 4096), dim3(BLOCK), 0, st, accum, n, scale, rgb8);

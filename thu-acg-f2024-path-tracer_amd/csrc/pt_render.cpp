@@ -290,6 +290,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (!hip_ok(hipMalloc((void**)&d_accum, accum_bytes), "hipMalloc(accum)")) return -1;
         own_accum.p = d_accum;
         if (!hip_ok(hipMemsetAsync(d_accum, 0, accum_bytes, st), "hipMemset(accum)")) return -1;
+    } else if (opts.overwrite) {
+        if (!hip_ok(hipMemsetAsync(d_accum, 0, accum_bytes, st), "hipMemset(accum)")) return -1;
     }
 
     // persistent grids: resident blocks per CU x CUs
@@ -322,6 +324,22 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;
+    // dynamic mode: the kernels add into channel planes in work-item (tile) order (PoolD::accum_tiled); k_detile adds them to d_accum
+    const bool tiled = dynamic && !exp_env("PT_ACCUM_LINEAR");
+    if (tiled) {
+        const size_t tb = (size_t)n_tile_pixels64 * 3 * sizeof(double);
+        if (tb > s->tile_accum_bytes) {
+            if (s->tile_accum) (void)hipFree(s->tile_accum);
+            s->tile_accum = nullptr;
+            s->tile_accum_bytes = 0;
+            if (!hip_ok(hipMalloc((void**)&s->tile_accum, tb), "hipMalloc(tiled accumulator)")) return -1;
+            s->tile_accum_bytes = tb;
+        }
+        if (!hip_ok(hipMemsetAsync(s->tile_accum, 0, tb, st), "hipMemset(tiled accumulator)")) return -1;
+        pool.accum = s->tile_accum;
+        pool.accum_tiled = 1u;
+    }
+    pool.inv_width = 1.0 / (double)dc.width;
     CountersD init_cnt;
     memset(&init_cnt, 0, sizeof init_cnt);
     init_cnt.alive = spp == 0 ? 0 : n_slots;   // every slot starts with one sample (k <= spp / n_slots <= total_work)
@@ -367,9 +385,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (alive && iterations > max_iterations + 128) return set_error("pt_render: iteration bound exceeded (internal error)");
         if (poll_every < 64) poll_every *= 2;
     }
-    if (!dynamic) {
+    if (!dynamic || tiled) {
         timer.begin(2, st);
-        launch_resolve(pool, d_accum, ctx->n_cus * 8, st);
+        if (tiled) launch_detile(pool, d_accum, ctx->n_cus * 8, st);
+        else launch_resolve(pool, d_accum, ctx->n_cus * 8, st);
         timer.end(st);
     }
     if (!hip_ok(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(CountersD), hipMemcpyDeviceToHost, st), "hipMemcpy(counters)")) return -1;
@@ -379,9 +398,13 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     if (!hip_ok(hipGetLastError(), "kernel launch")) return -1;
 
     if (!opts.accum_on_device) {
-        std::vector<double> tmp((size_t)n_pixels * 3);
-        if (!hip_ok(hipMemcpy(tmp.data(), d_accum, accum_bytes, hipMemcpyDeviceToHost), "hipMemcpy(accum)")) return -1;
-        for (size_t i = 0; i < tmp.size(); ++i) accum[i] += tmp[i];
+        if (opts.overwrite) {
+            if (!hip_ok(hipMemcpy(accum, d_accum, accum_bytes, hipMemcpyDeviceToHost), "hipMemcpy(accum)")) return -1;
+        } else {
+            std::vector<double> tmp((size_t)n_pixels * 3);
+            if (!hip_ok(hipMemcpy(tmp.data(), d_accum, accum_bytes, hipMemcpyDeviceToHost), "hipMemcpy(accum)")) return -1;
+            for (size_t i = 0; i < tmp.size(); ++i) accum[i] += tmp[i];
+        }
     }
     if (exp_env("PT_PROF")) {   // diagnostic builds (-DPT_STAMPS): wave-cycle sums per k_shade class
         static const char* names[N_CLASSES + 1] = {"miss", "diffuse", "metal", "glass", "principled", "light", "sheen", "clearcoat", "mix", "idle", "dead", "WINDOW"};

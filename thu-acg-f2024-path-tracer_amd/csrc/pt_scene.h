@@ -75,6 +75,8 @@ struct pt_scene {
     // path pool cache (re-used across pt_render calls of the same size)
     void* pool_mem = nullptr;
     size_t pool_bytes = 0;
+    double* tile_accum = nullptr;  // dynamic mode: the frame accumulator in tile order (PoolD::accum_tiled), re-used like the pool
+    size_t tile_accum_bytes = 0;
     pt::CountersD* d_counters = nullptr;
     pt::CountersD* h_counters = nullptr;   // pinned
     ~pt_scene();

@@ -205,7 +205,16 @@ struct PoolD {
                                                   // mode adds every contribution to the frame accumulator right away
     uint32_t* hit_prim;
     uint32_t* bounce;                             // bounce count, or SLOT_DEAD / SLOT_IDLE
-    double* accum;                                // dynamic mode: frame accumulator (W*H*3 sums)
+    double* accum;                                // dynamic mode: frame accumulator (W*H*3 sums). accum_tiled: three CHANNEL PLANES of
+                                                  // n_tile_pixels sums each, a plane in the order the work items are handed out — tile
+                                                  // after tile, 64 pixels of an 8x8 tile consecutive (index = plane + tile*64 + (y&7)*8 + (x&7)):
+                                                  // the lanes of a group that finish together mostly hold pixels of the same few tiles, so one
+                                                  // global_atomic_add_f64 wave-instruction covers runs of consecutive 8-byte words — whole 64-byte
+                                                  // memory-side atomic requests (MI355X_MICROARCH.md "Global float atomics": they execute at the
+                                                  // memory side, one request per 64 B touched) — instead of 64 requests at a 24-byte stride.
+                                                  // k_detile adds the planes to the caller's (y, x, c) accumulator once per render.
+    double inv_width;                             // 1 / width (pixel -> row by one multiplication and an exact correction)
+    uint32_t accum_tiled;
     unsigned long long total_work;                // dynamic mode: n_pixels * (spp_end - spp_begin)
     uint32_t n_slots, n_pixels, k;                // k = slots per pixel (static mode)
     uint32_t spp_begin, spp_end;
