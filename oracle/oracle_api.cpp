@@ -47,7 +47,6 @@ struct orc_scene {
     std::vector<TexSlot> tex;
     std::vector<std::shared_ptr<Material>> mats;
     std::vector<HitPtr> objs;
-    std::vector<char> placed, wrapped;   // per object: added to the world directly / wrapped by an Instance (ids: orc_core.h Instance)
     World world;
     bool built = false;
     std::map<std::string, std::shared_ptr<ImageRGB8>> images;
@@ -228,33 +227,22 @@ extern "C" int orc_mesh(orc_scene* s, double scale, uint32_t n_pos, const float*
     s->objs.push_back(std::make_shared<TriangleMesh>(scale, n_pos, pos, n_idx, idx, n_nrm, nrm, n_uv, uv, s->mats[mat]));
     return (int)s->objs.size() - 1;
 }
-// Instance::new takes an Arc<dyn Hittable> (instance.rs:20-30): the wrapped object may be shared by any number of
-// instances and may be an instance itself. The one restriction is the build's id scheme: an object is either placed
-// in the world directly (once) or wrapped — not both.
-static int mark(orc_scene* s, int obj, bool direct) {
-    s->placed.resize(s->objs.size(), 0);
-    s->wrapped.resize(s->objs.size(), 0);
-    if (direct ? (s->placed[obj] || s->wrapped[obj]) : s->placed[obj])
-        return fail(direct ? "object is already placed (directly, or through an instance)" : "object is already placed in the world");
-    (direct ? s->placed : s->wrapped)[obj] = 1;
-    return 0;
-}
+// Instance::new and World::add_object / add_light take an Arc<dyn Hittable> (instance.rs:20-30, world.rs:18-24): an object may be
+// shared by any number of instances, may be an instance itself, and may be added to the world directly any number of times as
+// well. Canonical primitive ids are per PLACEMENT (orc_core.h Placement / Instance::id_offset).
 extern "C" int orc_instance(orc_scene* s, int obj, const double axis[3], double angle, const double tr[3]) {
     CHECK_OBJ(s, obj);
-    if (mark(s, obj, false) != 0) return -1;
     s->objs.push_back(std::make_shared<Instance>(s->objs[obj], V(axis), angle, V(tr)));
     return (int)s->objs.size() - 1;
 }
 extern "C" int orc_world_add_object(orc_scene* s, int obj) {
     CHECK_OBJ(s, obj);
-    if (mark(s, obj, true) != 0) return -1;
-    s->world.objects.add(s->objs[obj]);
+    s->world.objects.add(std::make_shared<Placement>(s->objs[obj]));
     return 0;
 }
 extern "C" int orc_world_add_light(orc_scene* s, int obj) {
     CHECK_OBJ(s, obj);
-    if (mark(s, obj, true) != 0) return -1;
-    s->world.lights.add(s->objs[obj]);
+    s->world.lights.add(std::make_shared<Placement>(s->objs[obj]));
     return 0;
 }
 extern "C" int orc_world_build(orc_scene* s) {

@@ -1049,6 +1049,29 @@ struct Instance : Hittable {  // instance.rs — rotate then translate
     uint32_t prim_count() const override { return object->prim_count(); }
 };
 
+// One entry of a world list (World::add_object / add_light take any Arc<dyn Hittable>, world.rs:18-24 — the same object may be
+// added several times and may also sit under instances). Only the build's canonical primitive ids need this wrapper: the
+// object numbers its primitives locally from 0 and every PLACEMENT adds its own offset, exactly as Instance does; every other
+// call is forwarded unchanged (no arithmetic of its own).
+struct Placement : Hittable {
+    HitPtr object;
+    uint32_t id_offset = 0;
+    explicit Placement(HitPtr obj) : object(std::move(obj)) {}
+    bool intersects(const Ray& ray, Interval ray_t, HitInfo& out, Counters& c) const override {
+        if (!object->intersects(ray, ray_t, out, c)) return false;
+        out.prim_id += id_offset;
+        return true;
+    }
+    AABB bounding_box() const override { return object->bounding_box(); }
+    bool sample(V3 origin, double time, Rng& rng, V3& dir) const override { return object->sample(origin, time, rng, dir); }
+    double pdf(V3 origin, V3 direction, double time, Counters& c) const override { return object->pdf(origin, direction, time, c); }
+    uint32_t assign_ids(uint32_t first) override {
+        id_offset = first;
+        return first + object->assign_ids(0);
+    }
+    uint32_t prim_count() const override { return object->prim_count(); }
+};
+
 struct World {  // world.rs
     HittableList objects, lights;
     uint32_t n_prims = 0;

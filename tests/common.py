@@ -270,3 +270,37 @@ def shared_and_nested_instances_scene(shared=True):
     spec.add("world_build")
     spec.camera = default_camera(width=64, look_from=(0.0, 2.0, -6.5), look_at=(0.0, 0.9, 0.0), vfov=45.0, env_color=(0.05, 0.06, 0.09))
     return spec
+
+
+def free_placement_scene():
+    """World::add_object / add_light and Instance::new take any Arc<dyn Hittable> (world.rs:18-24, instance.rs:20-30): ONE
+    sphere, ONE cuboid and ONE mesh object are each placed in the world directly AND under instances (the mesh under two, one
+    of them nested), the sphere is added to the world twice (coincident placements: every hit of it is an exact t tie, decided
+    by the per-placement ids), and one quad is both a light of the lights list and, instanced, an ordinary object."""
+    spec = SceneSpec()
+    rgb = lambda r, g, b: spec.add("tex_solid_rgb", r, g, b)
+    floor = spec.add("mat_diffuse", spec.add("tex_checker", 0.7, rgb(0.25, 0.2, 0.3), rgb(0.9, 0.9, 0.85)), -1)
+    metal = spec.add("mat_metal", rgb(0.85, 0.8, 0.5), spec.add("tex_solid_f", 0.2))
+    glass = spec.add("mat_glass", rgb(1.0, 1.0, 1.0), spec.add("tex_solid_f", 0.1), 0.0, 1.5)
+    red = spec.add("mat_diffuse", rgb(0.8, 0.2, 0.15), -1)
+    spec.add("world_add_object", spec.add("quad", (-8.0, 0.0, -8.0), (0.0, 0.0, 16.0), (16.0, 0.0, 0.0), floor))
+    ball = spec.add("sphere", 0.5, (-2.2, 0.5, 0.0), (-2.2, 0.5, 0.0), metal)
+    spec.add("world_add_object", ball)
+    spec.add("world_add_object", ball)                                                       # the same Arc twice
+    spec.add("world_add_object", spec.add("instance", ball, (0.0, 1.0, 0.0), 0.4, (0.3, 0.6, 1.5)))
+    box = spec.add("cuboid", (0.0, 0.0, 0.0), (0.6, 0.8, 0.6), glass)
+    spec.add("world_add_object", box)
+    spec.add("world_add_object", spec.add("instance", box, (0.0, 1.0, 0.0), 0.7, (1.2, 0.0, -1.0)))
+    P, I = icosphere(1)
+    mesh = spec.add("mesh", 0.55, P, I, None, None, red)
+    spec.add("world_add_object", mesh)                                                       # mesh vertices sit around the origin
+    inner = spec.add("instance", mesh, (1.0, 0.0, 0.0), 0.9, (0.0, 1.4, 0.0))
+    spec.add("world_add_object", inner)
+    spec.add("world_add_object", spec.add("instance", inner, (0.0, 0.0, 1.0), -0.5, (2.0, 0.2, 0.6)))
+    lm = spec.add("mat_light", rgb(10.0, 9.0, 8.0))
+    lq = spec.add("quad", (-0.7, 3.5, -0.7), (1.4, 0.0, 0.0), (0.0, 0.0, 1.4), lm)
+    spec.add("world_add_light", lq)
+    spec.add("world_add_object", spec.add("instance", lq, (0.0, 0.0, 1.0), 0.3, (-3.0, 0.5, 1.0)))
+    spec.add("world_build")
+    spec.camera = default_camera(width=64, look_from=(0.0, 2.2, -6.0), look_at=(0.0, 0.8, 0.0), vfov=48.0, env_color=(0.06, 0.07, 0.1))
+    return spec

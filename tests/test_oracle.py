@@ -656,7 +656,7 @@ BIAS_SPHERE_LIGHT = 16.905   # E[reference estimator] / true integral - 1 for te
 def test_shared_and_nested_instances(orc):
     """Instance::new takes an Arc<dyn Hittable> (instance.rs:20-30): one mesh may sit under several instances and an
     instance may wrap an instance. Sharing must change nothing against three equal mesh objects (ids are per placement),
-    and an object cannot be both placed directly and wrapped."""
+    (Direct placements next to instances: test_an_object_may_be_placed_directly_and_under_instances.)"""
     from common import shared_and_nested_instances_scene
     accs = []
     for shared in (True, False):
@@ -669,14 +669,44 @@ def test_shared_and_nested_instances(orc):
         s.close()
     np.testing.assert_array_equal(accs[0][0], accs[1][0])
     assert accs[0][1] == accs[1][1] and np.isfinite(accs[0][0]).mean() > 0.99 and accs[0][0].max() > 0
+
+
+def test_an_object_may_be_placed_directly_and_under_instances(orc):
+    """world.rs:18-24 / instance.rs:20-30 take any Arc<dyn Hittable>: one object added to the world twice, and both directly
+    and under instances, must render exactly like separate equal objects would (ids are per placement)."""
+    from common import free_placement_scene
+    spec = free_placement_scene()
     s = orc.Scene()
-    m = s.mat_diffuse(s.tex_solid_rgb(1, 1, 1))
-    q = s.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
-    i1 = s.instance(q, (0, 1, 0), 0.1, (0, 0, 0))
-    s.instance(q, (0, 1, 0), 0.2, (1, 0, 0))                       # shared: fine
-    with pytest.raises(Exception, match="already placed"):
-        s.world_add_object(q)                                       # wrapped objects are not placed directly
-    s.world_add_object(i1)
-    with pytest.raises(Exception, match="already placed"):
-        s.instance(i1, (0, 1, 0), 0.1, (0, 0, 0))                   # and placed objects are not wrapped
+    cam = spec.make_camera(orc.Camera, spec.replay(s))
+    assert s.prim_count() == 1 + 3 * 1 + 2 * 6 + 3 * 80 + 2
+    a, ca = s.render(cam, 7, 0, 4)
     s.close()
+    # the same world with every placement given an object of its own, built by hand
+    s2 = orc.Scene()
+    rgb = s2.tex_solid_rgb
+    floor = s2.mat_diffuse(s2.tex_checker(0.7, rgb(0.25, 0.2, 0.3), rgb(0.9, 0.9, 0.85)), -1)
+    metal = s2.mat_metal(rgb(0.85, 0.8, 0.5), s2.tex_solid_f(0.2))
+    glass = s2.mat_glass(rgb(1.0, 1.0, 1.0), s2.tex_solid_f(0.1), 0.0, 1.5)
+    red = s2.mat_diffuse(rgb(0.8, 0.2, 0.15), -1)
+    s2.world_add_object(s2.quad((-8.0, 0.0, -8.0), (0.0, 0.0, 16.0), (16.0, 0.0, 0.0), floor))
+    ball = lambda: s2.sphere(0.5, (-2.2, 0.5, 0.0), (-2.2, 0.5, 0.0), metal)
+    s2.world_add_object(ball()); s2.world_add_object(ball())
+    s2.world_add_object(s2.instance(ball(), (0.0, 1.0, 0.0), 0.4, (0.3, 0.6, 1.5)))
+    box = lambda: s2.cuboid((0.0, 0.0, 0.0), (0.6, 0.8, 0.6), glass)
+    s2.world_add_object(box())
+    s2.world_add_object(s2.instance(box(), (0.0, 1.0, 0.0), 0.7, (1.2, 0.0, -1.0)))
+    from common import icosphere
+    P, I = icosphere(1)
+    mesh = lambda: s2.mesh(0.55, P, I, None, None, red)
+    s2.world_add_object(mesh())
+    s2.world_add_object(s2.instance(mesh(), (1.0, 0.0, 0.0), 0.9, (0.0, 1.4, 0.0)))
+    s2.world_add_object(s2.instance(s2.instance(mesh(), (1.0, 0.0, 0.0), 0.9, (0.0, 1.4, 0.0)), (0.0, 0.0, 1.0), -0.5, (2.0, 0.2, 0.6)))
+    lm = s2.mat_light(rgb(10.0, 9.0, 8.0))
+    lq = lambda: s2.quad((-0.7, 3.5, -0.7), (1.4, 0.0, 0.0), (0.0, 0.0, 1.4), lm)
+    s2.world_add_light(lq())
+    s2.world_add_object(s2.instance(lq(), (0.0, 0.0, 1.0), 0.3, (-3.0, 0.5, 1.0)))
+    s2.world_build()
+    b, cb = s2.render(cam, 7, 0, 4)
+    s2.close()
+    np.testing.assert_array_equal(a, b)
+    assert ca["segments"] == cb["segments"] and np.isfinite(a).all() and a.max() > 0

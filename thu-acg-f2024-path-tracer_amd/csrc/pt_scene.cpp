@@ -258,8 +258,7 @@ extern "C" int pt_mesh(pt_scene* s, double scale, uint32_t n_pos, const float* p
 }
 extern "C" int pt_instance(pt_scene* s, int obj, const double axis[3], double angle, const double tr[3]) {   // instance.rs:20-30
     if (!OBJ_OK(s, obj)) return set_error("pt_instance: bad object handle");
-    if (s->objs[obj].placed) return set_error("pt_instance: object is already placed in the world");
-    s->objs[obj].wrapped = true;   // may be wrapped again (shared geometry), and may itself be an instance (nesting)
+    // the wrapped object may be wrapped again (shared geometry), may itself be an instance (nesting) and may also be placed directly
     HostObj o;
     o.kind = OBJ_INSTANCE;
     o.child = obj;
@@ -289,8 +288,8 @@ extern "C" int pt_instance(pt_scene* s, int obj, const double axis[3], double an
 }
 static int place(pt_scene* s, int obj, std::vector<int>& list, const char* who) {
     if (!OBJ_OK(s, obj)) return set_error(std::string(who) + ": bad object handle");
-    if (s->objs[obj].placed || s->objs[obj].wrapped) return set_error(std::string(who) + ": object is already placed (directly, or through an instance)");
-    s->objs[obj].placed = true;
+    // World::add_object / add_light take any Arc<dyn Hittable> (world.rs:18-24): the same object any number of times, under instances
+    // as well. Every entry of the two lists is one PLACEMENT with its own primitive ids (scene_build).
     list.push_back(obj);
     s->built = false;
     return 0;

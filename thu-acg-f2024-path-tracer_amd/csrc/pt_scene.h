@@ -43,9 +43,8 @@ struct HostObj {
     bool has_normals = false, has_uvs = false;
     int child = -1;                 // instance
     InstD xf{};
-    // An object is either placed in the world directly (once) or wrapped by instances — any number of them, and an
-    // instance may wrap an instance (Instance::new takes an Arc<dyn Hittable>, instance.rs:20-30).
-    bool placed = false, wrapped = false;
+    // An object may be placed in the world directly any number of times and wrapped by any number of instances, and an instance
+    // may wrap an instance (Instance::new / World::add_object take an Arc<dyn Hittable>, instance.rs:20-30, world.rs:18-24).
 };
 
 struct DeviceBuffers {
