@@ -73,6 +73,13 @@ int pt_tex_solid_rgb(pt_scene*, double r, double g, double b);          /* Solid
 int pt_tex_solid_f(pt_scene*, double v);                                /* SolidTexture<f64>       */
 int pt_tex_checker(pt_scene*, double scale, int tex1, int tex2);        /* CheckerTexture::new :34-40 */
 int pt_tex_image_rgb8(pt_scene*, uint32_t w, uint32_t h, const uint8_t* rgb);   /* ImageTexture (decoded, RGB8) :56-70 */
+/* The float-HDR option: an ImageTexture that keeps the decoder's f32 samples instead of `.to_rgb8()`
+ * (texture.rs:67) — same nearest-texel lookup (texture.rs:73-91), values not clamped to [0,1]. Usable wherever an image texture
+ * is (colour, normal map, Camera::environment). pt_scene_set_float_hdr(scene, 1) makes the scene scripts (pt_build_scene) and the
+ * host mirrors load Radiance .hdr files this way; the default (0) is the reference's RGB8 behaviour. */
+int pt_tex_image_rgbf32(pt_scene*, uint32_t w, uint32_t h, const float* rgb);
+int pt_scene_set_float_hdr(pt_scene*, int on);
+int pt_scene_float_hdr(pt_scene*);
 /* ---- materials: src/bsdf/, src/material.rs ---------------------------------------------- */
 int pt_mat_diffuse(pt_scene*, int color_tex, int normal_map_tex);       /* DiffuseBRDF::{new,from_rgb,from_textures} diffuse.rs:21-47; -1 = no map */
 int pt_mat_metal(pt_scene*, int color_tex, int rough_tex);              /* MetalBRDF::new metal.rs:23-35 */
@@ -112,6 +119,7 @@ int pt_load_obj(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, 
 int pt_load_obj_single_index(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** nrm, uint32_t* n_nrm,
                              float** uv, uint32_t* n_uv);
 int pt_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);
+int pt_load_hdr_rgbf32(const char* path, float** rgb, uint32_t* w, uint32_t* h);   /* the same decode without .to_rgb8(): f32 RGB, free with pt_free */
 int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);   /* PNG -> RGB8 (alpha dropped like to_rgb8, texture.rs:67) */
 void pt_free(void*);
 /* images this library does not decode (JPEG): hand them over decoded, under the file name

@@ -47,6 +47,8 @@ int orc_tex_solid_rgb(orc_scene*, double r, double g, double b);
 int orc_tex_solid_f(orc_scene*, double v);
 int orc_tex_checker(orc_scene*, double scale, int tex1, int tex2);
 int orc_tex_image_rgb8(orc_scene*, uint32_t w, uint32_t h, const uint8_t* rgb);
+int orc_tex_image_rgbf32(orc_scene*, uint32_t w, uint32_t h, const float* rgb);   /* f32 samples kept (no to_rgb8 squash) */
+int orc_scene_set_float_hdr(orc_scene*, int on);   /* scene scripts load .hdr files as f32 */
 /* materials (bsdf/, material.rs:150-191) */
 int orc_mat_diffuse(orc_scene*, int color_tex, int normal_map_tex /* -1 = none */);
 int orc_mat_metal(orc_scene*, int color_tex, int rough_tex);
@@ -73,6 +75,7 @@ uint32_t orc_world_prim_count(orc_scene*);
 int orc_load_obj(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx,
                  float** uv, uint32_t* n_uv);
 int orc_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);
+int orc_load_hdr_rgbf32(const char* path, float** rgb, uint32_t* w, uint32_t* h);
 void orc_free(void*);
 /* decoded images the oracle cannot decode itself (JPEG/PNG), looked up by the built-in
  * scenes under the file name the reference opens (e.g. "envmap.jpg", "bricks/color.png") */

@@ -49,6 +49,7 @@ struct orc_scene {
     std::vector<HitPtr> objs;
     World world;
     bool built = false;
+    bool float_hdr = false;   // scene scripts load .hdr files as f32 (orc_scene_set_float_hdr)
     std::map<std::string, std::shared_ptr<ImageRGB8>> images;
 };
 
@@ -91,6 +92,18 @@ extern "C" int orc_tex_image_rgb8(orc_scene* s, uint32_t w, uint32_t h, const ui
     t.rgb = t.img;
     s->tex.push_back(t);
     return (int)s->tex.size() - 1;
+}
+extern "C" int orc_tex_image_rgbf32(orc_scene* s, uint32_t w, uint32_t h, const float* rgb) {   // float samples kept (ImageRGB8::pf)
+    if (!rgb && w != 0 && h != 0) return fail("null image");
+    TexSlot t;
+    t.img = std::make_shared<ImageRGB8>(w, h, rgb);
+    t.rgb = t.img;
+    s->tex.push_back(t);
+    return (int)s->tex.size() - 1;
+}
+extern "C" int orc_scene_set_float_hdr(orc_scene* s, int on) {
+    s->float_hdr = on != 0;
+    return 0;
 }
 extern "C" int orc_mat_diffuse(orc_scene* s, int color_tex, int nmap) {
     CHECK_TEX_RGB(s, color_tex);
@@ -305,9 +318,9 @@ extern "C" int orc_load_obj(const char* path, float** pos, uint32_t* n_pos, uint
     return 0;
 }
 
-// Radiance .hdr -> RGB8 as image 0.25.5 does for `decode().to_rgb8()` (texture.rs:62-67):
-// RGBE -> f32 (mantissa * 2^(e-136), e==0 -> 0) -> round(clamp(x,0,1)*255).
-extern "C" int orc_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h) {
+// Radiance .hdr -> f32 RGB as image 0.25.5's HdrDecoder does (RGBE -> mantissa * 2^(e-136), e == 0 -> 0); the RGB8 form is
+// `decode().to_rgb8()` (texture.rs:62-67): round(clamp(x,0,1)*255).
+static int load_hdr_f32(const char* path, std::vector<float>& out, uint32_t* w, uint32_t* h) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(std::string("cannot open ") + path);
     char line[512];
@@ -325,47 +338,63 @@ extern "C" int orc_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, u
             break;
         }
     }
-    if (W <= 0 || H <= 0) { fclose(f); return fail("bad HDR header"); }
+    if (W <= 0 || H <= 0 || (uint64_t)W * (uint64_t)H > (1ull << 28)) { fclose(f); return fail("bad HDR header"); }
     std::vector<uint8_t> scan((size_t)W * 4);
-    uint8_t* out = (uint8_t*)malloc((size_t)W * H * 3);
+    out.assign((size_t)W * H * 3, 0.0f);
     for (int y = 0; y < H; ++y) {
         uint8_t hd[4];
-        if (fread(hd, 1, 4, f) != 4) { fclose(f); free(out); return fail("truncated HDR"); }
+        if (fread(hd, 1, 4, f) != 4) { fclose(f); return fail("truncated HDR"); }
         if (hd[0] == 2 && hd[1] == 2 && (hd[2] & 0x80) == 0 && ((hd[2] << 8) | hd[3]) == W) {
             for (int c = 0; c < 4; ++c) {  // new-style RLE, channel-planar per scanline
                 int x = 0;
                 while (x < W) {
                     int n = fgetc(f);
-                    if (n == EOF) { fclose(f); free(out); return fail("truncated HDR"); }
+                    if (n == EOF) { fclose(f); return fail("truncated HDR"); }
                     if (n > 128) {
                         n -= 128;
                         int v = fgetc(f);
-                        if (x + n > W) { fclose(f); free(out); return fail("bad HDR run"); }
+                        if (v == EOF || x + n > W) { fclose(f); return fail("bad HDR run"); }
                         while (n--) scan[(size_t)(x++) * 4 + c] = (uint8_t)v;
                     } else {
-                        if (x + n > W) { fclose(f); free(out); return fail("bad HDR run"); }
-                        while (n--) scan[(size_t)(x++) * 4 + c] = (uint8_t)fgetc(f);
+                        if (n == 0 || x + n > W) { fclose(f); return fail("bad HDR run"); }
+                        while (n--) {
+                            int v = fgetc(f);
+                            if (v == EOF) { fclose(f); return fail("truncated HDR"); }
+                            scan[(size_t)(x++) * 4 + c] = (uint8_t)v;
+                        }
                     }
                 }
             }
         } else {  // flat RGBE scanline
             memcpy(scan.data(), hd, 4);
-            if (fread(scan.data() + 4, 1, (size_t)(W - 1) * 4, f) != (size_t)(W - 1) * 4) { fclose(f); free(out); return fail("truncated HDR"); }
+            if (fread(scan.data() + 4, 1, (size_t)(W - 1) * 4, f) != (size_t)(W - 1) * 4) { fclose(f); return fail("truncated HDR"); }
         }
         for (int x = 0; x < W; ++x) {
             const uint8_t* p = &scan[(size_t)x * 4];
-            for (int c = 0; c < 3; ++c) {
-                float v = 0.0f;
-                if (p[3] != 0) v = (float)p[c] * ldexpf(1.0f, (int)p[3] - 136);
-                float cl = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                out[((size_t)y * W + x) * 3 + c] = (uint8_t)roundf(cl * 255.0f);
-            }
+            for (int c = 0; c < 3; ++c) out[((size_t)y * W + x) * 3 + c] = p[3] != 0 ? (float)p[c] * ldexpf(1.0f, (int)p[3] - 136) : 0.0f;
         }
     }
     fclose(f);
-    *rgb = out;
     *w = (uint32_t)W;
     *h = (uint32_t)H;
+    return 0;
+}
+extern "C" int orc_load_hdr_rgbf32(const char* path, float** rgb, uint32_t* w, uint32_t* h) {
+    std::vector<float> v;
+    if (load_hdr_f32(path, v, w, h) != 0) return -1;
+    *rgb = (float*)malloc(v.size() * sizeof(float) + 4);
+    memcpy(*rgb, v.data(), v.size() * sizeof(float));
+    return 0;
+}
+extern "C" int orc_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h) {
+    std::vector<float> v;
+    if (load_hdr_f32(path, v, w, h) != 0) return -1;
+    uint8_t* out = (uint8_t*)malloc(v.size() + 4);
+    for (size_t i = 0; i < v.size(); ++i) {
+        float cl = v[i] < 0.0f ? 0.0f : (v[i] > 1.0f ? 1.0f : v[i]);
+        out[i] = (uint8_t)roundf(cl * 255.0f);
+    }
+    *rgb = out;
     return 0;
 }
 
@@ -406,8 +435,15 @@ struct SceneBuilder {
             return (int)s->tex.size() - 1;
         }
         if (name.size() > 4 && name.substr(name.size() - 4) == ".hdr") {
-            uint8_t* rgb;
             uint32_t w, h;
+            if (s->float_hdr) {   // the build's option: keep the decoder's f32 samples (no to_rgb8 squash)
+                float* rgbf;
+                if (orc_load_hdr_rgbf32((dir + "/" + name).c_str(), &rgbf, &w, &h) != 0) return -1;
+                int t = orc_tex_image_rgbf32(s, w, h, rgbf);
+                free(rgbf);
+                return t;
+            }
+            uint8_t* rgb;
             if (orc_load_hdr_rgb8((dir + "/" + name).c_str(), &rgb, &w, &h) != 0) return -1;
             int t = orc_tex_image_rgb8(s, w, h, rgb);
             free(rgb);

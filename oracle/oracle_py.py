@@ -55,6 +55,9 @@ def _load():
     lib.orc_tex_solid_f.argtypes = [C.c_void_p, C.c_double]
     lib.orc_tex_checker.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
     lib.orc_tex_image_rgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.orc_tex_image_rgbf32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.orc_scene_set_float_hdr.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_load_hdr_rgbf32.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.orc_mat_diffuse.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.orc_mat_metal.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.orc_mat_glass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
@@ -159,6 +162,13 @@ class Scene:
         img = np.ascontiguousarray(img, dtype=np.uint8)
         h, w = img.shape[:2]
         return _check(lib.orc_tex_image_rgb8(self.handle, w, h, img.ctypes.data))
+
+    def tex_image_rgbf32(self, img):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        h, w = img.shape[:2]
+        return _check(lib.orc_tex_image_rgbf32(self.handle, w, h, img.ctypes.data))
+
+    def set_float_hdr(self, on=True): return _check(lib.orc_scene_set_float_hdr(self.handle, 1 if on else 0))
 
     def mat_diffuse(self, color_tex, normal_map_tex=-1): return _check(lib.orc_mat_diffuse(self.handle, color_tex, normal_map_tex))
     def mat_metal(self, color_tex, rough_tex): return _check(lib.orc_mat_metal(self.handle, color_tex, rough_tex))
@@ -267,6 +277,15 @@ def load_obj(path):
     T = np.ctypeslib.as_array(uv, (nuv.value * 2,)).copy().reshape(-1, 2) if nuv.value else np.zeros((0, 2), np.float32)
     lib.orc_free(pos); lib.orc_free(idx); lib.orc_free(uv)
     return P, I, T
+
+
+def load_hdr_rgbf32(path):
+    p = C.POINTER(C.c_float)()
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib.orc_load_hdr_rgbf32(path.encode(), C.byref(p), C.byref(w), C.byref(h)), "orc_load_hdr_rgbf32")
+    img = np.ctypeslib.as_array(p, (h.value, w.value, 3)).copy()
+    lib.orc_free(p)
+    return img
 
 
 def load_hdr_rgb8(path):

@@ -98,7 +98,12 @@ struct CheckerRGB : TexRGB {  // texture.rs:27-54
 struct ImageRGB8 : TexRGB {  // texture.rs:56-92 — always RGB8, nearest texel
     uint32_t w, h;
     std::vector<uint8_t> px;
+    // The build's float-HDR option ("native float HDR envmaps, bypassing the to_rgb8 squash texture.rs:67,
+    // behind a flag"): the image keeps the decoder's f32 samples — `ImageReader::decode()` of a Radiance file yields Rgb32F — and
+    // the lookup of texture.rs:73-91 returns them widened to f64 instead of byte / 255. Same texel addressing.
+    std::vector<float> pf;
     ImageRGB8(uint32_t w_, uint32_t h_, const uint8_t* data) : w(w_), h(h_), px(data, data + (size_t)w_ * h_ * 3) {}
+    ImageRGB8(uint32_t w_, uint32_t h_, const float* data) : w(w_), h(h_), pf(data, data + (size_t)w_ * h_ * 3) {}
     V3 value(double u, double v, V3) const override {
         if (h == 0) return V3{0.0, 1.0, 1.0};
         u = clampd(u, 0.0, 1.0);
@@ -108,6 +113,10 @@ struct ImageRGB8 : TexRGB {  // texture.rs:56-92 — always RGB8, nearest texel
         // Q6: the reference panics for i==w / j==h (u==1 or v==0); the build clamps.
         if (i > w - 1) i = w - 1;
         if (j > h - 1) j = h - 1;
+        if (!pf.empty()) {
+            const float* q = &pf[((size_t)j * w + i) * 3];
+            return V3{(double)q[0], (double)q[1], (double)q[2]};
+        }
         const uint8_t* p = &px[((size_t)j * w + i) * 3];
         const double s = 1.0 / 255.0;
         return V3{s * (double)p[0], s * (double)p[1], s * (double)p[2]};

@@ -748,6 +748,40 @@ def test_objects_placed_directly_and_under_instances_bit_exact(pt, det, ctx):
     gs.close(); os_.close()
 
 
+def test_float_hdr_environment_and_textures_bit_exact(pt, det, ctx, scene_images):
+    """The float-HDR option (pt_scene_set_float_hdr / pt_tex_image_rgbf32): scenes 4 and 6 with grace_probe_latlong.hdr kept as
+    f32 samples — no .to_rgb8() squash (texture.rs:67), same lookup (texture.rs:73-91) — and a float image used as a quad's colour
+    texture: every accumulator value equals the oracle's twin; the frames are brighter than the RGB8 ones (the probe's lights
+    reach 1088 where RGB8 stops at 1)."""
+    for sid, width, spp in ((4, 96, 6), (6, 112, 6)):
+        gs, os_ = pt.Scene(ctx), det.Scene()
+        gs.set_float_hdr(True); os_.set_float_hdr(True)
+        gcam = gs.build_scene(sid, width, spp)
+        ocam = os_.build_scene(sid, width, spp, images=scene_images(sid))
+        ga, st = gs.render(gcam, 1, 0, spp, slots_per_pixel=1)
+        oa, cnt = os_.render(ocam, 1, 0, spp)
+        np.testing.assert_array_equal(ga, oa)
+        assert st.segments == cnt["segments"]
+        g8 = pt.Scene(ctx)
+        a8, _ = g8.render(g8.build_scene(sid, width, spp), 1, 0, spp, slots_per_pixel=1)
+        assert ga.sum() > 1.5 * a8.sum() and ga.max() > 100 * spp * 0.01
+        gs.close(); os_.close(); g8.close()
+    rng = np.random.default_rng(5)
+    img = (rng.random((8, 16, 3)) * 6.0).astype(np.float32)
+    spec = SceneSpec()
+    t = spec.add("tex_image_rgbf32", img)
+    spec.add("world_add_object", spec.add("quad", (-2.0, 0.0, -2.0), (0.0, 0.0, 4.0), (4.0, 0.0, 0.0), spec.add("mat_diffuse", t, -1)))
+    spec.add("world_add_object", spec.add("sphere", 0.6, (0.0, 0.6, 0.0), (0.0, 0.6, 0.0), spec.add("mat_metal", t, spec.add("tex_solid_f", 0.3))))
+    spec.add("world_build")
+    spec.camera = default_camera(width=48, look_from=(0.0, 2.5, -4.0), look_at=(0.0, 0.3, 0.0), vfov=50.0, env_color=(0.6, 0.7, 0.9))
+    gs, os_ = pt.Scene(ctx), det.Scene()
+    gcam, ocam = spec.make_camera(pt.Camera, spec.replay(gs)), spec.make_camera(det.Camera, spec.replay(os_))
+    ga, _ = gs.render(gcam, 2, 0, 8, slots_per_pixel=1)
+    oa, _ = os_.render(ocam, 2, 0, 8)
+    np.testing.assert_array_equal(ga, oa)
+    gs.close(); os_.close()
+
+
 def test_device_bvh_builder_bit_exact(pt, det, ctx):
     """pt_world_set_device_bvh_threshold: mesh BVHs built by the GPU LBVH builder (csrc/pt_bvh_device.hip) instead of the host's
     binned SAH. The closest hit is tree-independent (minimum t, ties -> larger id), so hits, segment counts and every

@@ -132,7 +132,8 @@ def test_png_decoder_matches_pillow_and_roundtrips(pt, tmp_path):
     for name, img in cases.items():
         path = str(tmp_path / f"{name}.png")
         img.save(path)
-        want = np.asarray(Image.open(path).convert("RGB")) if name != "grey16" else np.repeat((np.asarray(img) >> 8).astype(np.uint8)[..., None], 3, axis=2)
+        # 16-bit samples: image 0.25.5's to_rgb8 converts u16 -> u8 as (v + 128) / 257 (rounded; Pillow's own conversion truncates)
+        want = np.asarray(Image.open(path).convert("RGB")) if name != "grey16" else np.repeat(((np.asarray(img).astype(np.uint32) + 128) // 257).astype(np.uint8)[..., None], 3, axis=2)
         np.testing.assert_array_equal(pt.load_png_rgb8(path), want, err_msg=name)
     png = str(tmp_path / "w.png")                              # the library's own writer (camera.rs:118) read back by its reader
     px = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)

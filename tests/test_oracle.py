@@ -710,3 +710,35 @@ def test_an_object_may_be_placed_directly_and_under_instances(orc):
     s2.close()
     np.testing.assert_array_equal(a, b)
     assert ca["segments"] == cb["segments"] and np.isfinite(a).all() and a.max() > 0
+
+
+def test_float_hdr_images_keep_the_decoders_samples(orc, pt):
+    """The float-HDR option (SURVEY §8f rank 3): a Radiance file decodes to f32 RGB (image's HdrDecoder: mantissa * 2^(e-136));
+    the reference then squashes it with .to_rgb8() (texture.rs:67) — round(clamp(x, 0, 1) * 255) — and the option skips exactly
+    that step. Both hosts' decoders agree bit for bit; an environment looked up through texture.rs:73-91 returns texel / 255 in
+    the RGB8 form and the f32 sample itself, widened, in the float form (values far above 1 survive)."""
+    path = os.path.join(pt.ASSET_DIR, "grace_probe_latlong.hdr")
+    f = orc.load_hdr_rgbf32(path)
+    assert f.dtype == np.float32 and f.shape == (512, 1024, 3) and f.max() > 500 and f.min() >= 0
+    np.testing.assert_array_equal(f, pt.load_hdr_rgbf32(path))
+    q = np.round(np.clip(f, 0, 1) * np.float32(255)).astype(np.uint8)
+    np.testing.assert_array_equal(q, orc.load_hdr_rgb8(path))
+    np.testing.assert_array_equal(q, pt.load_hdr_rgb8(path))
+    # a 4x2 float image as the environment of an (almost) empty world: every camera sample returns one of its texels
+    img = np.array([[[0.25, 0.5, 1.0], [2.0, 3.0, 4.0], [100.0, 0.0, 7.5], [1e-3, 1e3, 1.0]],
+                    [[9.0, 8.0, 7.0], [0.5, 0.5, 0.5], [40.0, 50.0, 60.0], [0.0, 0.0, 0.0]]], dtype=np.float32)
+    out = {}
+    for kind in ("f32", "u8"):
+        s = orc.Scene()
+        m = s.mat_diffuse(s.tex_solid_rgb(0.5, 0.5, 0.5))
+        s.world_add_object(s.sphere(1e-3, (0, -50, 0), (0, -50, 0), m))
+        t = s.tex_image_rgbf32(img) if kind == "f32" else s.tex_image_rgb8(np.round(np.clip(img, 0, 1) * 255).astype(np.uint8))
+        s.world_build()
+        cam = orc.Camera(); cam.aspect_ratio = 1.0; cam.image_width = 16; cam.vfov = 90; cam.max_depth = 3
+        cam.look_at[2] = 1.0; cam.vup[1] = 1.0; cam.focal_length = 1.0; cam.env_is_map = 1; cam.env_tex = t; cam.blur_strength = 0.5
+        out[kind], _ = s.render(cam, 1, 0, 1)
+        s.close()
+    texels = {tuple(float(x) for x in px) for px in img.reshape(-1, 3)}
+    assert {tuple(px) for px in out["f32"].reshape(-1, 3)} <= texels and out["f32"].max() >= 40.0
+    assert out["u8"].max() <= 1.0
+    assert {tuple(px) for px in out["u8"].reshape(-1, 3)} <= {tuple((1.0 / 255.0) * float(b) for b in np.round(np.clip(px, 0, 1) * 255)) for px in img.reshape(-1, 3)}

@@ -87,12 +87,12 @@ class RenderStats(C.Structure):
 ABI_SYMBOLS = [
     "pt_last_error", "pt_set_error_message", "pt_ctx_create", "pt_ctx_destroy", "pt_device_name",
     "pt_scene_create", "pt_scene_destroy", "pt_scene_ctx",
-    "pt_tex_solid_rgb", "pt_tex_solid_f", "pt_tex_checker", "pt_tex_image_rgb8",
+    "pt_tex_solid_rgb", "pt_tex_solid_f", "pt_tex_checker", "pt_tex_image_rgb8", "pt_tex_image_rgbf32", "pt_scene_set_float_hdr", "pt_scene_float_hdr",
     "pt_mat_diffuse", "pt_mat_metal", "pt_mat_glass", "pt_mat_principled", "pt_mat_light", "pt_mat_mix", "pt_mat_sheen", "pt_mat_clearcoat",
     "pt_sphere", "pt_quad", "pt_cuboid", "pt_mesh", "pt_instance",
     "pt_world_add_object", "pt_world_add_light", "pt_world_build", "pt_world_prim_count",
     "pt_world_set_device_bvh_threshold", "pt_world_device_bvh_info",
-    "pt_load_obj", "pt_load_obj_single_index", "pt_load_hdr_rgb8", "pt_load_png_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
+    "pt_load_obj", "pt_load_obj_single_index", "pt_load_hdr_rgb8", "pt_load_hdr_rgbf32", "pt_load_png_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
     "pt_build_scene", "pt_camera_init", "pt_render", "pt_resolve_u8", "pt_intersect", "pt_math_probe",
     "pt_shard_range", "pt_comm_create", "pt_comm_destroy", "pt_comm_rank", "pt_comm_world", "pt_comm_barrier", "pt_comm_allreduce_f64",
     "pt_bootstrap_exchange", "pt_render_multi",
@@ -121,6 +121,10 @@ def _load():
     lib.pt_tex_solid_f.argtypes = [C.c_void_p, C.c_double]
     lib.pt_tex_checker.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
     lib.pt_tex_image_rgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.pt_tex_image_rgbf32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.pt_scene_set_float_hdr.argtypes = [C.c_void_p, C.c_int]
+    lib.pt_scene_float_hdr.argtypes = [C.c_void_p]
+    lib.pt_load_hdr_rgbf32.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pt_mat_diffuse.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pt_mat_metal.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pt_mat_glass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
@@ -296,6 +300,16 @@ class Scene:
         h, w = img.shape[:2]
         return _check(lib.pt_tex_image_rgb8(self.handle, w, h, img.ctypes.data), "tex_image_rgb8")
 
+    def tex_image_rgbf32(self, img: np.ndarray):
+        """ImageTexture that keeps f32 samples (no to_rgb8 squash, texture.rs:67): the float-HDR option."""
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        h, w = img.shape[:2]
+        return _check(lib.pt_tex_image_rgbf32(self.handle, w, h, img.ctypes.data), "tex_image_rgbf32")
+
+    def set_float_hdr(self, on: bool = True):
+        """Scene scripts (build_scene) load Radiance .hdr files as f32 textures from now on."""
+        return _check(lib.pt_scene_set_float_hdr(self.handle, 1 if on else 0), "set_float_hdr")
+
     def mat_diffuse(self, color_tex, normal_map_tex=-1): return _check(lib.pt_mat_diffuse(self.handle, color_tex, normal_map_tex), "mat_diffuse")
     def mat_metal(self, color_tex, rough_tex): return _check(lib.pt_mat_metal(self.handle, color_tex, rough_tex), "mat_metal")
     def mat_glass(self, color_tex, rough_tex, aniso, ior): return _check(lib.pt_mat_glass(self.handle, color_tex, rough_tex, aniso, ior), "mat_glass")
@@ -444,6 +458,16 @@ def load_png_rgb8(path: str) -> np.ndarray:
     p = C.POINTER(C.c_uint8)()
     w, h = C.c_uint32(), C.c_uint32()
     _check(lib.pt_load_png_rgb8(path.encode(), C.byref(p), C.byref(w), C.byref(h)), "pt_load_png_rgb8")
+    img = np.ctypeslib.as_array(p, (h.value, w.value, 3)).copy()
+    lib.pt_free(p)
+    return img
+
+
+def load_hdr_rgbf32(path: str) -> np.ndarray:
+    """Radiance .hdr -> f32 RGB (the decode of texture.rs:62-66 WITHOUT .to_rgb8())."""
+    p = C.POINTER(C.c_float)()
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib.pt_load_hdr_rgbf32(path.encode(), C.byref(p), C.byref(w), C.byref(h)), "pt_load_hdr_rgbf32")
     img = np.ctypeslib.as_array(p, (h.value, w.value, 3)).copy()
     lib.pt_free(p)
     return img

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -25,10 +26,28 @@ static T* to_malloc(const std::vector<T>& v) {
     return p;
 }
 
+// Untrusted files: decoded sizes are bounded before anything is allocated, and no C++ exception (std::bad_alloc from a hostile
+// header, std::length_error) crosses the C ABI — every extern "C" loader of this file runs its body through guarded().
+static const uint64_t MAX_IMAGE_PIXELS = 1ull << 28;   // 268 M pixels: 3 GiB as f32 RGB — far above any asset, far below a size_t overflow
+// every extern "C" loader runs inside this: a std::bad_alloc / length_error from a hostile header must not cross the C ABI
+template <class F>
+static int guarded(const char* who, F&& f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        return set_error(std::string(who) + ": " + e.what());
+    } catch (...) {
+        return set_error(std::string(who) + ": unexpected failure");
+    }
+}
 // Positions and texcoords are parsed as f32 (tobj does); faces are fan-triangulated; only the
 // position index of each `v/vt/vn` corner is kept, 1-based or negative-relative -> 0-based u32.
+static int load_obj(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** uv, uint32_t* n_uv);
 extern "C" int pt_load_obj(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** uv,
                            uint32_t* n_uv) {
+    return guarded("pt_load_obj", [&]() { return load_obj(path, pos, n_pos, idx, n_idx, uv, n_uv); });
+}
+static int load_obj(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** uv, uint32_t* n_uv) {
     std::ifstream in(path);
     if (!in) return set_error(std::string("pt_load_obj: cannot open ") + path);
     std::vector<float> P, T;
@@ -77,8 +96,14 @@ extern "C" int pt_load_obj(const char* path, float** pos, uint32_t* n_pos, uint3
 // attribute lookup is right for any file. n_nrm / n_uv are 0 when the file has no vn / vt, or when a face omits them.
 #include <map>
 #include <tuple>
+static int load_obj_single_index(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** nrm, uint32_t* n_nrm,
+                                 float** uv, uint32_t* n_uv);
 extern "C" int pt_load_obj_single_index(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** nrm,
                                         uint32_t* n_nrm, float** uv, uint32_t* n_uv) {
+    return guarded("pt_load_obj_single_index", [&]() { return load_obj_single_index(path, pos, n_pos, idx, n_idx, nrm, n_nrm, uv, n_uv); });
+}
+static int load_obj_single_index(const char* path, float** pos, uint32_t* n_pos, uint32_t** idx, uint32_t* n_idx, float** nrm, uint32_t* n_nrm,
+                                 float** uv, uint32_t* n_uv) {
     std::ifstream in(path);
     if (!in) return set_error(std::string("pt_load_obj_single_index: cannot open ") + path);
     std::vector<float> P, T, N, oP, oT, oN;
@@ -139,10 +164,10 @@ extern "C" int pt_load_obj_single_index(const char* path, float** pos, uint32_t*
     return 0;
 }
 
-// PNG -> RGB8 (role of image's PngDecoder + to_rgb8(), texture.rs:62-67: alpha dropped, grey replicated, 16-bit samples
-// keep their high byte, palettes expanded). zlib inflates the IDAT stream; the five scanline filters are undone here.
+// PNG -> RGB8 (role of image's PngDecoder + to_rgb8(), texture.rs:62-67: alpha dropped, grey replicated, palettes expanded,
+// 16-bit samples reduced as image 0.25.5 converts u16 -> u8: (v + 128) / 257, i.e. rounded, not truncated). zlib inflates the IDAT stream; the five scanline filters are undone here.
 // Interlaced (Adam7) files are rejected.
-extern "C" int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h) {
+static int load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h) {
     std::ifstream in(path, std::ios::binary);
     if (!in) return set_error(std::string("pt_load_png_rgb8: cannot open ") + path);
     std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
@@ -167,11 +192,13 @@ extern "C" int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, ui
         else if (type == "IEND") break;
         p += 12 + (size_t)len;
     }
-    if (W == 0 || H == 0 || (uint64_t)W * H > (1ull << 31)) return set_error("pt_load_png_rgb8: bad image size");
+    if (W == 0 || H == 0 || (uint64_t)W * H > MAX_IMAGE_PIXELS) return set_error("pt_load_png_rgb8: bad image size");
+    if (idat.size() > 0xFFFFFFFFull) return set_error("pt_load_png_rgb8: image data too large");
     if (interlace) return set_error("pt_load_png_rgb8: interlaced PNG is not supported");
     const int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!chans || !(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
         return set_error("pt_load_png_rgb8: unsupported colour type / bit depth");
+    if (ctype == 3 && depth == 16) return set_error("pt_load_png_rgb8: a palette image cannot have 16-bit indices");
     if (ctype == 3 && plte.size() < 3) return set_error("pt_load_png_rgb8: palette image without PLTE");
     const size_t bpp = std::max<size_t>(1, (size_t)chans * depth / 8), stride = ((size_t)W * chans * depth + 7) / 8;
     std::vector<uint8_t> raw((stride + 1) * H);
@@ -197,7 +224,11 @@ extern "C" int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, ui
         memcpy(prev.data(), cur, stride);
         auto sample = [&](uint32_t x, int ch) -> uint8_t {   // 8-bit value of channel ch of pixel x
             if (depth == 8) return cur[(size_t)x * chans + ch];
-            if (depth == 16) return cur[((size_t)x * chans + ch) * 2];
+            if (depth == 16) {   // big-endian u16 -> u8 like image's to_rgb8: (v + 128) / 257
+                const size_t k = ((size_t)x * chans + ch) * 2;
+                const uint32_t v16 = ((uint32_t)cur[k] << 8) | cur[k + 1];
+                return (uint8_t)((v16 + 128u) / 257u);
+            }
             const size_t bit = (size_t)x * depth;
             const int v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
             return ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
@@ -219,59 +250,83 @@ extern "C" int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, ui
     *w = W; *h = H;
     return 0;
 }
+extern "C" int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h) {
+    return guarded("pt_load_png_rgb8", [&]() { return load_png_rgb8(path, rgb, w, h); });
+}
 
-// RGBE -> f32 (mantissa * 2^(e-136), e == 0 -> 0) -> round(clamp(x,0,1)*255), the image
-// crate's HDR -> Rgb8 conversion. Handles new-style per-channel RLE and flat scanlines.
-extern "C" int pt_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h) {
+// Radiance RGBE -> f32 (mantissa * 2^(e-136), e == 0 -> 0), the image crate's HdrDecoder. Handles new-style per-channel RLE and
+// flat scanlines. Untrusted input: the header's size is bounded before anything is allocated, every run is checked against the
+// scanline and the file's end, and no exception leaves this file's extern "C" functions (guarded()).
+static int load_hdr_f32(const char* who, const char* path, std::vector<float>& out, uint32_t* w, uint32_t* h) {
     std::ifstream in(path, std::ios::binary);
-    if (!in) return set_error(std::string("pt_load_hdr_rgb8: cannot open ") + path);
+    if (!in) return set_error(std::string(who) + ": cannot open " + path);
     std::string line;
-    if (!std::getline(in, line) || line.compare(0, 2, "#?") != 0) return set_error("pt_load_hdr_rgb8: not a Radiance file");
+    if (!std::getline(in, line) || line.compare(0, 2, "#?") != 0) return set_error(std::string(who) + ": not a Radiance file");
     while (std::getline(in, line) && !line.empty()) {}
-    if (!std::getline(in, line)) return set_error("pt_load_hdr_rgb8: missing resolution line");
+    if (!std::getline(in, line)) return set_error(std::string(who) + ": missing resolution line");
     int W = 0, H = 0;
-    if (sscanf(line.c_str(), "-Y %d +X %d", &H, &W) != 2 || W <= 0 || H <= 0) return set_error("pt_load_hdr_rgb8: unsupported orientation");
+    if (sscanf(line.c_str(), "-Y %d +X %d", &H, &W) != 2 || W <= 0 || H <= 0) return set_error(std::string(who) + ": unsupported orientation");
+    if ((uint64_t)W * (uint64_t)H > MAX_IMAGE_PIXELS) return set_error(std::string(who) + ": image too large");
     std::vector<uint8_t> rest((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     size_t p = 0;
-    auto need = [&](size_t n) { return p + n <= rest.size(); };
-    std::vector<uint8_t> out((size_t)W * H * 3), scan((size_t)W * 4);
+    auto need = [&](size_t n) { return n <= rest.size() && p <= rest.size() - n; };
+    std::vector<uint8_t> scan((size_t)W * 4);
+    out.assign((size_t)W * H * 3, 0.0f);
     for (int y = 0; y < H; ++y) {
-        if (!need(4)) return set_error("pt_load_hdr_rgb8: truncated file");
+        if (!need(4)) return set_error(std::string(who) + ": truncated file");
         const bool rle = rest[p] == 2 && rest[p + 1] == 2 && (rest[p + 2] & 0x80) == 0 && ((rest[p + 2] << 8) | rest[p + 3]) == W;
         if (rle) {
             p += 4;
             for (int c = 0; c < 4; ++c)
                 for (int x = 0; x < W;) {
-                    if (!need(1)) return set_error("pt_load_hdr_rgb8: truncated file");
+                    if (!need(1)) return set_error(std::string(who) + ": truncated file");
                     int n = rest[p++];
                     if (n > 128) {
                         n -= 128;
-                        if (!need(1) || x + n > W) return set_error("pt_load_hdr_rgb8: bad run");
+                        if (!need(1) || x + n > W) return set_error(std::string(who) + ": bad run");
                         uint8_t v = rest[p++];
                         while (n--) scan[(size_t)(x++) * 4 + c] = v;
                     } else {
-                        if (!need((size_t)n) || x + n > W) return set_error("pt_load_hdr_rgb8: bad run");
+                        if (n == 0 || !need((size_t)n) || x + n > W) return set_error(std::string(who) + ": bad run");
                         while (n--) scan[(size_t)(x++) * 4 + c] = rest[p++];
                     }
                 }
         } else {
-            if (!need((size_t)W * 4)) return set_error("pt_load_hdr_rgb8: truncated file");
+            if (!need((size_t)W * 4)) return set_error(std::string(who) + ": truncated file");
             memcpy(scan.data(), &rest[p], (size_t)W * 4);
             p += (size_t)W * 4;
         }
         for (int x = 0; x < W; ++x) {
             const uint8_t* q = &scan[(size_t)x * 4];
-            for (int c = 0; c < 3; ++c) {
-                float v = q[3] ? (float)q[c] * std::ldexp(1.0f, (int)q[3] - 136) : 0.0f;
-                v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                out[((size_t)y * W + x) * 3 + c] = (uint8_t)std::round(v * 255.0f);
-            }
+            for (int c = 0; c < 3; ++c) out[((size_t)y * W + x) * 3 + c] = q[3] ? (float)q[c] * std::ldexp(1.0f, (int)q[3] - 136) : 0.0f;
         }
     }
-    *rgb = to_malloc(out);
     *w = (uint32_t)W;
     *h = (uint32_t)H;
     return 0;
+}
+// ImageReader::open(..).decode() of a Radiance file: Rgb32F, kept as it is (the float-HDR option, pt_tex_image_rgbf32)
+extern "C" int pt_load_hdr_rgbf32(const char* path, float** rgb, uint32_t* w, uint32_t* h) {
+    return guarded("pt_load_hdr_rgbf32", [&]() {
+        std::vector<float> v;
+        if (load_hdr_f32("pt_load_hdr_rgbf32", path, v, w, h) != 0) return -1;
+        *rgb = to_malloc(v);
+        return 0;
+    });
+}
+// ... followed by .to_rgb8() (texture.rs:62-67): round(clamp(x,0,1)*255)
+extern "C" int pt_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h) {
+    return guarded("pt_load_hdr_rgb8", [&]() {
+        std::vector<float> v;
+        if (load_hdr_f32("pt_load_hdr_rgb8", path, v, w, h) != 0) return -1;
+        std::vector<uint8_t> out(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            const float c = v[i] < 0.0f ? 0.0f : (v[i] > 1.0f ? 1.0f : v[i]);
+            out[i] = (uint8_t)std::round(c * 255.0f);
+        }
+        *rgb = to_malloc(out);
+        return 0;
+    });
 }
 extern "C" void pt_free(void* p) { free(p); }
 

@@ -45,6 +45,10 @@ PT_DEV V3 tex_image(const SceneD& sc, const TexD& T, double u, double v) {   // 
     uint32_t j = f64_as_u32(v * (double)T.h);
     if (i > T.w - 1) i = T.w - 1;      // Q6: the reference would panic at u==1 / v==0
     if (j > T.h - 1) j = T.h - 1;
+    if (T.kind == TEX_IMAGE_F32) {     // float samples, no RGB8 squash (pt_types.h)
+        const float* q = sc.atlas_f + T.ofs + ((size_t)j * T.w + i) * 3;
+        return V3{(double)q[0], (double)q[1], (double)q[2]};
+    }
     const uint8_t* p = sc.atlas + T.ofs + ((size_t)j * T.w + i) * 3;
     const double s = 1.0 / 255.0;
     return V3{s * (double)p[0], s * (double)p[1], s * (double)p[2]};
@@ -58,7 +62,7 @@ PT_DEV V3 tex_rgb(const SceneD& sc, int32_t t, double u, double v, V3 p) {
             t = (int32_t)(first ? T.t1 : T.t2);
             continue;
         }
-        if (T.kind == TEX_IMAGE) return tex_image(sc, T, u, v);
+        if (T.kind == TEX_IMAGE || T.kind == TEX_IMAGE_F32) return tex_image(sc, T, u, v);
         return V3{T.v[0], T.v[1], T.v[2]};
     }
     return V3{0.0, 0.0, 0.0};

@@ -32,6 +32,8 @@ constexpr int SORT_WINDOW_SLOTS = 2048;   // window size of k_extend2 and k_shad
 // (BVH, primitives: a few MB) are re-read by every wave: the result leaves with non-temporal stores.
 // (Non-temporal LOADS of the path records made no measurable difference and are not used.)
 template <class T> PT_DEV void stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+typedef __attribute__((address_space(3))) void* lds_ptr;      // operands of __builtin_amdgcn_global_load_lds (LDS-DMA)
+typedef const __attribute__((address_space(1))) void* glb_ptr;
 
 // ---- path records (pt_types.h RayRec / PathRec): one lane moves one whole record, 16 B per access ----
 typedef double d2v __attribute__((ext_vector_type(2)));
@@ -899,27 +901,40 @@ PT_DEV SlotIn load_slot_global(const PoolD& pool, uint32_t s, bool enable, const
 }
 // Asynchronous fetch of a group's records into the wave's LDS staging area: `global_load_lds` (LDS-DMA) — the data goes
 // from HBM to LDS without passing through (or occupying) a single vector register, which is the only way this kernel, at its
-// 256-register limit, can have the NEXT group's 6 KB in flight while it computes on the current one. Layout: chunk c of
-// lane l at stage[c][l] (lane-linear, as the instruction writes: M0 base + lane * size): RayRec = chunks 0..3, PathRec = 4..5.
+// 256-register limit, can have the NEXT group's 6 KB in flight while it computes on the current one.
+// [r3] WHOLE SECTORS per instruction. A lane used to fetch the six 16-byte pieces of ITS OWN records, so every wave-instruction
+// touched 64 different 64-byte sectors for 16 bytes each and every sector was requested by four instructions (the L2 saw 4x the
+// transactions, and a streaming cache policy could not be used: the pieces of a record must find the sector their sibling
+// fetched). Now instruction k serves the records of lanes 16k .. 16k+15 with FOUR lanes per RayRec (two per PathRec), each
+// fetching a different piece: 16 (32) whole sectors per instruction, every byte requested exactly once. The LDS image —
+// wave-uniform base + lane * 16, as the instruction writes — is then simply the records in lane order: RayRec of lane l at
+// stage[4 l .. 4 l + 3], PathRec at stage[256 + 2 l ..]. The slots of the other lanes come by ds_bpermute.
 // Must be executed by ALL 64 lanes (wave-uniform control flow).
-constexpr int STAGE_CHUNKS = 6;
-typedef __attribute__((address_space(3))) void* lds_ptr;
-typedef const __attribute__((address_space(1))) void* glb_ptr;
-PT_DEV void stage_fetch(const PoolD& pool, uint32_t s, uint4 (*stage)[64]) {
-    const char* r = reinterpret_cast<const char*>(&pool.ray[s]);
-    const char* p = reinterpret_cast<const char*>(&pool.path[s]);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(r), (lds_ptr)&stage[0][0], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(r + 16), (lds_ptr)&stage[1][0], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(r + 32), (lds_ptr)&stage[2][0], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(r + 48), (lds_ptr)&stage[3][0], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(p), (lds_ptr)&stage[4][0], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(p + 16), (lds_ptr)&stage[5][0], 16, 0, 0);
+#ifndef PT_STAGE_AUX
+#define PT_STAGE_AUX 0             // cache policy of the record stream: 0 default, 2 = nt (MI355X_MICROARCH.md row "nt-weights")
+#endif
+constexpr int STAGE_CHUNKS = 6;     // 16-byte pieces per lane: the staging area of a wave is uint4[STAGE_CHUNKS * 64]
+PT_DEV void stage_fetch(const PoolD& pool, uint32_t s, uint4* stage, int lane) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sk = (uint32_t)__shfl((int)s, (lane >> 2) + 16 * k);
+        const char* g = reinterpret_cast<const char*>(&pool.ray[sk]) + 16 * (lane & 3);
+        __builtin_amdgcn_global_load_lds((glb_ptr)g, (lds_ptr)(stage + 64 * k), 16, 0, PT_STAGE_AUX);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const uint32_t sm = (uint32_t)__shfl((int)s, (lane >> 1) + 32 * m);
+        const char* g = reinterpret_cast<const char*>(&pool.path[sm]) + 16 * (lane & 1);
+        __builtin_amdgcn_global_load_lds((glb_ptr)g, (lds_ptr)(stage + 256 + 64 * m), 16, 0, PT_STAGE_AUX);
+    }
 }
 // the staged records of this lane (after the issuing wave's s_waitcnt vmcnt(0): nothing else orders an LDS read behind an LDS-DMA)
-PT_DEV SlotIn load_slot_stage(const PoolD& pool, const uint4 (*stage)[64], int lane, bool enable, uint32_t hw) {
+PT_DEV SlotIn load_slot_stage(const PoolD& pool, const uint4* stage, int lane, bool enable, uint32_t hw) {
     SlotIn in{};
     in.hw = hw;
-    const uint4 a = stage[0][lane], b = stage[1][lane], c = stage[2][lane], d = stage[3][lane], e = stage[4][lane], f = stage[5][lane];
+    const uint4* rr = stage + 4 * lane;
+    const uint4* pr = stage + 256 + 2 * lane;
+    const uint4 a = rr[0], b = rr[1], c = rr[2], d = rr[3], e = pr[0], f = pr[1];
     auto f64 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
     in.ray = RayD{V3{f64(a.x, a.y), f64(a.z, a.w), f64(b.x, b.y)}, V3{f64(b.z, b.w), f64(c.x, c.y), f64(c.z, c.w)}, pool.compact ? 0.0 : f64(d.x, d.y)};
     in.sample = d.z;
@@ -1199,7 +1214,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
         constexpr uint32_t NCLASS = N_CLASSES, K_DEAD = CLASS_DEAD;   // miss, one per material kind, idle, dead
         __shared__ uint32_t s_cnt[NCLASS][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
         __shared__ uint32_t s_hist[NCLASS], s_next;
-        __shared__ uint4 s_stage[BLOCK / 64][STAGE_CHUNKS][64];   // 24 KB: one staging area per wave (stage_fetch)
+        __shared__ uint4 s_stage[BLOCK / 64][STAGE_CHUNKS * 64];   // 24 KB: one staging area per wave (stage_fetch)
         constexpr int PER = SORT_WINDOW / BLOCK, NGRP = SORT_WINDOW / 64;
         const int wave = (int)(threadIdx.x >> 6);
         __shared__ uint32_t s_win;
@@ -1297,7 +1312,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             // point where the current group's arithmetic can hide the fetch; the first group of a window comes straight from
             // the pool. Dynamic mode only (the static mode's extra per-slot arrays are not staged).
             const bool use_stage = PT_K3_PREFETCH && pool.dynamic != 0u;
-            uint4 (*stage)[64] = s_stage[wave];
+            uint4* stage = s_stage[wave];
             uint32_t g = grab();
             bool staged = false;
             while (g < n_groups) {
@@ -1325,7 +1340,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                         bool en;
                         const uint32_t sn = slot_of(g_next, en);
                         __builtin_amdgcn_sched_barrier(0);            // nothing of the current group's loads may sink below the DMA
-                        stage_fetch(pool, sn, stage);
+                        stage_fetch(pool, sn, stage, lane);
                         __builtin_amdgcn_sched_barrier(0);
                         staged_next = true;
                     }

@@ -195,7 +195,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         dc.motionless = s->motionless && !exp_env("PT_DRAW_TIME") ? 1u : 0u;
     }
     if (dc.env_is_map) {
-        if (cam->env_tex < 0 || (size_t)cam->env_tex >= s->tex.size() || s->tex[cam->env_tex].d.kind != TEX_IMAGE)
+        if (cam->env_tex < 0 || (size_t)cam->env_tex >= s->tex.size() || (s->tex[cam->env_tex].d.kind != TEX_IMAGE && s->tex[cam->env_tex].d.kind != TEX_IMAGE_F32))
             return set_error("pt_render: env_tex must be an image texture of this scene");
     }
     const uint64_t n_pixels64 = (uint64_t)dc.width * dc.height;

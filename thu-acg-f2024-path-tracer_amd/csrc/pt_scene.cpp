@@ -89,6 +89,21 @@ extern "C" int pt_tex_image_rgb8(pt_scene* s, uint32_t w, uint32_t h, const uint
     t.is_rgb = true;
     return push_tex(s, std::move(t));
 }
+extern "C" int pt_tex_image_rgbf32(pt_scene* s, uint32_t w, uint32_t h, const float* rgb) {
+    if (!rgb && w != 0 && h != 0) return set_error("pt_tex_image_rgbf32: null pixels");
+    HostTex t;
+    t.d.kind = TEX_IMAGE_F32;
+    t.d.w = w; t.d.h = h;
+    t.image_f.assign(rgb, rgb + (size_t)w * h * 3);
+    t.is_rgb = true;
+    return push_tex(s, std::move(t));
+}
+extern "C" int pt_scene_set_float_hdr(pt_scene* s, int on) {
+    if (!s) return set_error("pt_scene_set_float_hdr: null scene");
+    s->float_hdr = on != 0;
+    return 0;
+}
+extern "C" int pt_scene_float_hdr(pt_scene* s) { return s && s->float_hdr ? 1 : 0; }
 extern "C" int pt_register_image(pt_scene* s, const char* name, uint32_t w, uint32_t h, const uint8_t* rgb) {
     int t = pt_tex_image_rgb8(s, w, h, rgb);
     if (t < 0) return -1;
@@ -113,7 +128,7 @@ extern "C" int pt_mat_diffuse(pt_scene* s, int color_tex, int nmap) {
     MatD m = blank_mat(MAT_DIFFUSE);
     m.color_tex = color_tex;
     if (nmap >= 0) {
-        if (!TEX_RGB_OK(s, nmap) || s->tex[nmap].d.kind != TEX_IMAGE) return set_error("pt_mat_diffuse: normal map must be an image texture");
+        if (!TEX_RGB_OK(s, nmap) || (s->tex[nmap].d.kind != TEX_IMAGE && s->tex[nmap].d.kind != TEX_IMAGE_F32)) return set_error("pt_mat_diffuse: normal map must be an image texture");
         m.nmap_tex = nmap;
     }
     return push_mat(s, m);
@@ -671,11 +686,15 @@ int pt::scene_build(pt_scene* s) {
     // texture atlas
     std::vector<TexD> tex(s->tex.size());
     std::vector<uint8_t> atlas;
+    std::vector<float> atlas_f;
     for (size_t i = 0; i < s->tex.size(); ++i) {
         tex[i] = s->tex[i].d;
         if (tex[i].kind == TEX_IMAGE) {
             tex[i].ofs = atlas.size();
             atlas.insert(atlas.end(), s->tex[i].image.begin(), s->tex[i].image.end());
+        } else if (tex[i].kind == TEX_IMAGE_F32) {
+            tex[i].ofs = atlas_f.size();
+            atlas_f.insert(atlas_f.end(), s->tex[i].image_f.begin(), s->tex[i].image_f.end());
         }
     }
     for (TexD& t : tex)   // checkers of two solid children carry the children's values
@@ -733,7 +752,7 @@ int pt::scene_build(pt_scene* s) {
     bool ok = upload(dev, nodes, v.nodes) && upload(dev, entries, v.entries) && upload(dev, prims, v.prims) &&
               upload(dev, spheres, v.spheres) && upload(dev, quads, v.quads) && upload(dev, tris, v.tris) &&
               upload(dev, tri_gid, v.tri_gid) && upload(dev, insts, v.insts) && upload(dev, tex, v.tex) &&
-              upload(dev, mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, lights, v.lights) && upload(dev, entry_box, v.entry_box);
+              upload(dev, mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, atlas_f, v.atlas_f) && upload(dev, lights, v.lights) && upload(dev, entry_box, v.entry_box);
     if (ok && any_attr) ok = upload(dev, tri_attr, v.tri_attr);
     if (!ok) {
         dev.release();

@@ -31,6 +31,7 @@ enum ObjKind { OBJ_SPHERE, OBJ_QUAD, OBJ_CUBOID, OBJ_MESH, OBJ_INSTANCE };
 struct HostTex {
     TexD d{};
     std::vector<uint8_t> image;   // TEX_IMAGE payload (RGB8)
+    std::vector<float> image_f;   // TEX_IMAGE_F32 payload (RGB f32)
     bool is_rgb = false;
 };
 struct HostObj {
@@ -63,6 +64,7 @@ struct pt_scene {
     std::vector<int> world_objects, world_lights;
     std::map<std::string, int> images;   // registered image name -> texture handle
     bool built = false;
+    bool float_hdr = false;        // scene scripts / host mirrors load Radiance files as f32 textures (pt_scene_set_float_hdr)
     uint32_t n_prims = 0;
     uint32_t n_mesh_entries = 0;   // world-level triangle meshes (picks the K2 variant)
     bool motionless = false;       // no sphere moves (p1 == p2 everywhere): a ray's time never reaches an arithmetic result

@@ -84,13 +84,15 @@ struct InstD {
 };
 
 // ---- textures / materials ------------------------------------------------------------
-enum TexKind : uint32_t { TEX_SOLID_RGB = 0, TEX_SOLID_F = 1, TEX_CHECKER = 2, TEX_IMAGE = 3 };
+// TEX_IMAGE_F32: ImageTexture WITHOUT the `.to_rgb8()` squash of texture.rs:67 — the decoder's f32 samples (a Radiance .hdr decodes to
+// Rgb32F) live in SceneD::atlas_f and the lookup of texture.rs:73-91 returns them widened to f64 (behind a flag).
+enum TexKind : uint32_t { TEX_SOLID_RGB = 0, TEX_SOLID_F = 1, TEX_CHECKER = 2, TEX_IMAGE = 3, TEX_IMAGE_F32 = 4 };
 struct TexD {
     uint32_t kind, t1, t2, w, h;
     uint32_t flat;       // TEX_CHECKER whose two children are solid: their values sit in c1 / c2 — one level less in the chain of
                          // DEPENDENT loads primitive -> material -> texture -> child texture (~700 cycles each in k_shade).
                          // (Also copying the descriptors into the material record made k_shade spill 384 B per lane.)
-    uint64_t ofs;        // byte offset into the RGB8 atlas
+    uint64_t ofs;        // byte offset into the RGB8 atlas (TEX_IMAGE) / element offset into the f32 atlas (TEX_IMAGE_F32)
     double v[3];
     double inv_scale;
     double c1[3], c2[3];
@@ -141,6 +143,7 @@ struct SceneD {
     const TexD* tex;
     const MatD* mats;
     const uint8_t* atlas;
+    const float* atlas_f;        // f32 RGB texels of the TEX_IMAGE_F32 textures
     const uint32_t* lights;      // entry indices of the lights list
     uint32_t tlas_root;          // child reference of the top-level root
     float tlas_extent;           // max |coordinate| of the top-level BVH boxes

@@ -1,6 +1,7 @@
 // CLI with the reference's two flags (src/main.rs:620-645): -q/--quality toggles
 // 1920 px @ 4000 spp vs 600 px @ 100 spp, -s/--scene N picks the scene script. Extra,
-// explicit overrides (not in the reference): --width, --spp, --seed, --out, --assets, --device.
+// explicit overrides (not in the reference): --width, --spp, --seed, --out, --assets, --device, --float-hdr
+// (.hdr environments keep their f32 samples instead of the reference's .to_rgb8() squash, texture.rs:67).
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -10,7 +11,7 @@
 using namespace path_tracer;
 
 int main(int argc, char** argv) {
-    bool quality = false;
+    bool quality = false, float_hdr = false;
     int scene = 1, device = 0;
     long width = -1, spp = -1;
     uint64_t seed = 1;
@@ -29,8 +30,9 @@ int main(int argc, char** argv) {
         else if (a == "--out") out = next();
         else if (a == "--assets") assets = next();
         else if (a == "--device") device = atoi(next());
+        else if (a == "--float-hdr") float_hdr = true;
         else if (a == "-h" || a == "--help") {
-            std::cout << "usage: pt_render [-q] [-s N] [--width W] [--spp S] [--seed K] [--out file.png] [--assets DIR] [--device D]\n";
+            std::cout << "usage: pt_render [-q] [-s N] [--width W] [--spp S] [--seed K] [--out file.png] [--assets DIR] [--device D] [--float-hdr]\n";
             return 0;
         } else { std::cerr << "unknown argument " << a << "\n"; return 2; }
     }
@@ -45,6 +47,7 @@ int main(int argc, char** argv) {
     }
     try {
         SceneSetup setup = make_scene(scene, w, s, assets, 1);
+        setup.world.float_hdr = float_hdr;
         setup.world.build_bvh(ctx, setup.camera.environment.is_map ? setup.camera.environment.map : nullptr);
         setup.camera.init();
         std::cerr << "rendering production\n";   // camera.rs:101

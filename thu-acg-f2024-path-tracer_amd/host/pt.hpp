@@ -356,10 +356,12 @@ struct World {
         scene = s;
         handles = e.done;
     }
+    bool float_hdr = false;   // this build's option: Radiance .hdr images keep their f32 samples (no .to_rgb8(), texture.rs:67)
     void build_bvh(pt_ctx* ctx, std::shared_ptr<ImageTexture> env = nullptr) {
         pt_scene* s = pt_scene_create(ctx);
         if (!s) panic("pt_scene_create");
         owns_scene = true;
+        if (float_hdr) pt_scene_set_float_hdr(s, 1);
         emit_into(s, env);
     }
     void release() {
@@ -451,7 +453,12 @@ inline int ImageTexture::emit(Emitter& e) const {
     const std::string path = e.asset_dir + "/" + key;
     uint8_t* rgb = nullptr;
     uint32_t w = 0, hh = 0;
-    if (key.size() > 4 && key.substr(key.size() - 4) == ".hdr") {
+    if (key.size() > 4 && key.substr(key.size() - 4) == ".hdr" && pt_scene_float_hdr(e.scene)) {   // the float-HDR option: no to_rgb8()
+        float* rgbf = nullptr;
+        if (pt_load_hdr_rgbf32(path.c_str(), &rgbf, &w, &hh) != 0) panic("ImageTexture::new(" + filename + ")");
+        h = pt_tex_image_rgbf32(e.scene, w, hh, rgbf);
+        pt_free(rgbf);
+    } else if (key.size() > 4 && key.substr(key.size() - 4) == ".hdr") {
         if (pt_load_hdr_rgb8(path.c_str(), &rgb, &w, &hh) != 0) panic("ImageTexture::new(" + filename + ")");
         h = pt_tex_image_rgb8(e.scene, w, hh, rgb);
         pt_free(rgb);
