@@ -185,6 +185,8 @@ MIS_SPHERE = ((0.0, 2.0, 0.0), 0.4)
 MIS_TRI = ((0.9, 2.0, -0.4), (1.9, 2.0, 0.1), (1.0, 2.0, 0.8))          # the one-triangle mesh light of the two-light scene
 MIS_TRI_EMISSION = (3.0, 6.0, 9.0)
 MIS_QUAD2 = ((-1.6, 2.0, -0.5), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0))           # the quad, moved aside so that the two never overlap in direction
+MIS_BOX = ((-0.5, 2.0, -0.4), (0.5, 2.5, 0.4))                                 # a cuboid light (cuboid.rs:78-84)
+MIS_INST = ((1.0, 0.0, 0.0), 0.6, (0.3, 0.4, -1.0))                             # Instance::new(quad MIS_QUAD, axis, angle, translation): a TILTED quad light
 MIS_CAM = dict(width=24, aspect=1.0, vfov=50.0, look_from=(0.0, 1.0, 0.0), look_at=(0.0, 0.0, 0.0), vup=(0.0, 0.0, 1.0), focal_length=1.0)
 
 
@@ -195,6 +197,10 @@ def mis_scene(light):
     lm = s.add("mat_light", s.add("tex_solid_rgb", *MIS_EMISSION))
     if light == "quad":
         s.add("world_add_light", s.add("quad", *MIS_QUAD, lm))
+    elif light == "cuboid":
+        s.add("world_add_light", s.add("cuboid", *MIS_BOX, lm))
+    elif light == "instquad":
+        s.add("world_add_light", s.add("instance", s.add("quad", *MIS_QUAD, lm), *MIS_INST))
     elif light == "two":
         s.add("world_add_light", s.add("quad", *MIS_QUAD2, lm))
         lt = s.add("mat_light", s.add("tex_solid_rgb", *MIS_TRI_EMISSION))
@@ -221,6 +227,10 @@ def mis_expected(light):
     pts = pts + np.array([0.0, 1e-3, 0.0])          # the second segment starts EPS above the surface (camera.rs:217-222)
     if light == "quad":
         est = true = R.quad_light_floor_radiance(pts, MIS_ALBEDO, MIS_EMISSION, *MIS_QUAD)
+    elif light == "cuboid":
+        est = true = R.box_light_floor_radiance(pts, MIS_ALBEDO, MIS_EMISSION, *MIS_BOX)
+    elif light == "instquad":
+        est = true = R.quad_light_floor_radiance(pts, MIS_ALBEDO, MIS_EMISSION, *R.rigid_quad(*MIS_QUAD, *MIS_INST))
     elif light == "two":
         tri = [np.array(p, dtype=np.float32).astype(np.float64) for p in MIS_TRI]      # the mesh stores f32 positions
         q, u, v = (np.asarray(a, float) for a in MIS_QUAD2)

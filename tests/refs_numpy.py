@@ -317,3 +317,48 @@ def coplanar_lights_floor_radiance(points, albedo, lights, eps=1e-3, n_big=28, n
             true[k] += alb / math.pi * le * first
             est[k] += alb / math.pi * le * (first + extra)
     return est, true
+
+
+# ---- Cuboid::{sample,pdf} (cuboid.rs:78-84 -> list.rs:78-96 over the six sides) and Instance::{sample,pdf} (instance.rs:64-75) ----
+def box_light_floor_radiance(points, albedo, emission, lo, hi, n_quad=40):
+    """A cuboid emitter [lo, hi] over a Lambert floor (normal +y), max_depth = 2. Cuboid::sample picks one of the SIX sides
+    uniformly and a uniform point on it; Cuboid::pdf is the MEAN over the six sides of dist^2 / (|cos| area) for every side
+    the ray from the floor point meets — entry AND exit side. A direction through the box is therefore proposed with density
+    (1/6) sum over the sides it meets of r^2 / (|cos| A), which is exactly the claimed pdf: the one-sample MIS estimator is
+    unbiased, whichever side a sampled point lay on (the next segment sees the entry side either way, and the emitter
+    radiates from both faces, material.rs:181-183). So E = (albedo/pi) Le * integral over the box's solid angle of cos_x dw
+    = sum over the sides FACING the point of the form factor (a convex body: each direction is counted once)."""
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    P = np.asarray(points, float).reshape(-1, 3)
+    s = (np.arange(n_quad) + 0.5) / n_quad
+    S, T = np.meshgrid(s, s, indexing="ij")
+    form = np.zeros(len(P))
+    for axis in range(3):
+        a, b = (axis + 1) % 3, (axis + 2) % 3
+        for side, coord in ((-1.0, lo[axis]), (1.0, hi[axis])):
+            pts = np.zeros(S.shape + (3,))
+            pts[..., axis] = coord
+            pts[..., a] = lo[a] + S * (hi[a] - lo[a])
+            pts[..., b] = lo[b] + T * (hi[b] - lo[b])
+            n_out = np.zeros(3); n_out[axis] = side
+            dA = (hi[a] - lo[a]) * (hi[b] - lo[b]) / (n_quad * n_quad)
+            for k in range(0, len(P), 512):
+                w = pts[None] - P[k:k + 512, None, None, :]
+                r2 = np.sum(w * w, axis=-1)
+                r = np.sqrt(r2)
+                cos_x = np.maximum(w[..., 1] / r, 0.0)
+                cos_l = np.maximum(-(w @ n_out) / r, 0.0)                 # only the sides whose OUTWARD normal faces the point
+                form[k:k + 512] += np.sum(cos_x * cos_l / r2, axis=(1, 2)) * dA
+    return (np.asarray(albedo, float)[None, :] / math.pi) * np.asarray(emission, float)[None, :] * form[:, None]
+
+
+def rigid_quad(q, u, v, axis, angle, translation):
+    """Instance::new(object, axis, angle, translation) (instance.rs:20-30): rotate about `axis` by `angle` (right-handed,
+    Rodrigues' formula — not the quaternion route of glam that the restatements take), then translate. Returns the world-space
+    (q, u, v) of a quad wrapped by that instance."""
+    k = np.asarray(axis, float)
+    k = k / np.linalg.norm(k)
+    K = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+    Rm = np.eye(3) + math.sin(angle) * K + (1.0 - math.cos(angle)) * (K @ K)
+    q, u, v = (np.asarray(a, float) for a in (q, u, v))
+    return Rm @ q + np.asarray(translation, float), Rm @ u, Rm @ v

@@ -546,14 +546,15 @@ def test_cli_renders_scene3_like_the_reference_binary(pt, det, ctx, tmp_path):
 
 
 # ---- the lights / MIS branch against deterministic quadrature (no reference image exists for scenes with lights) ----------
-@pytest.mark.parametrize("light", ["quad", "sphere", "two"])
+@pytest.mark.parametrize("light", ["quad", "sphere", "two", "cuboid", "instquad"])
 def test_light_sampling_mis_matches_quadrature(pt, ctx, light):
     """The HIP path's one-sample MIS (camera.rs:199-216, list.rs:78-96, quad.rs:80-98 / sphere.rs:110-135) against numbers
     that come from neither the oracle nor the kernels: tests/refs_numpy.py integrates what trace() computes in expectation
     for a Lambert floor under one emitter (max_depth = 2, so quirk Q5 cannot act). Quad light: the estimator is unbiased and
     the pixel must equal (albedo/pi) Le x form factor. Sphere light: the reference's Sphere::pdf is not the density of
     Sphere::sample — its estimator is ~18x too bright — and THAT value must be reproduced. "two": a lights list of a quad and a
-    one-triangle mesh (uniform pick, mean of pdfs, list.rs:78-96; Triangle::sample / pdf, mesh.rs:122-141). Every pixel within Monte-Carlo
+    one-triangle mesh (uniform pick, mean of pdfs, list.rs:78-96; Triangle::sample / pdf, mesh.rs:122-141). "cuboid" / "instquad":
+    a cuboid light (cuboid.rs:78-84) and a tilted quad light under an Instance (instance.rs:64-75), both unbiased. Every pixel within Monte-Carlo
     error (16 batches of 256 spp: z ~ t(15)), the image mean within 4 sigma."""
     from common import mis_scene, mis_expected, mis_zscores
     spec = mis_scene(light)

@@ -650,6 +650,20 @@ def test_two_lights_list_mixture_and_triangle_light_match_quadrature(orc):
     assert (zt < -5).all(), zt                                             # and measurably away from the true integral
 
 
+@pytest.mark.parametrize("light", ["cuboid", "instquad"])
+def test_cuboid_and_instanced_lights_match_quadrature(orc, light):
+    """Second, independent readings of the last two light kinds that only had GPU == oracle:
+    Cuboid::{sample,pdf} (cuboid.rs:78-84: the six sides as a HittableList — uniform pick, MEAN of the six quad pdfs, entry and
+    exit side both counted) and Instance::{sample,pdf} (instance.rs:64-75: origin and direction into the local frame, the
+    sampled direction back out) around a TILTED quad light. Both estimators are unbiased (sampler density == claimed pdf), so a
+    Lambert floor must show (albedo/pi) Le x the emitter's form factor — integrated in numpy over the box's facing sides /
+    over the quad moved by Rodrigues' rotation formula (refs_numpy.box_light_floor_radiance, rigid_quad)."""
+    z, zg, mean = _oracle_mis(orc, light)
+    assert np.isfinite(z).all() and mean.min() > 0.02
+    assert np.abs(zg).max() < 4.0, zg
+    assert (np.abs(z) > 4.0).mean() < 0.01 and 0.85 < z.std() < 1.3, (np.abs(z).max(), z.std())
+
+
 BIAS_SPHERE_LIGHT = 16.905   # E[reference estimator] / true integral - 1 for tests/common.py's MIS_SPHERE set-up (quadrature, refs_numpy.py)
 
 
