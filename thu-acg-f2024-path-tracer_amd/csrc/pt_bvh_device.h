@@ -14,6 +14,8 @@ struct DeviceBlas {
     int depth = 0;                  // deepest leaf, counted like the host builder's depth_reached
 };
 // false: nothing built (too few triangles, a tree deeper than max_depth, or a HIP error) — build on the host instead
+// median_below: subtrees of at most this many triangles are split in the middle of their (Morton-sorted) run instead of at the
+// code's highest differing bit — balanced bottoms leave the depth budget to the upper levels, where the Morton splits matter
 bool build_blas_device(const TriD* tris, uint32_t n, const double mesh_lo[3], const double mesh_hi[3], uint32_t leaf_max, uint32_t max_depth,
-                       DeviceBlas& out, hipStream_t st);
+                       uint32_t median_below, DeviceBlas& out, hipStream_t st);
 }  // namespace pt

@@ -8,7 +8,7 @@
 // here renders bit for bit like one built on the host (tests/test_gpu_parity.py::test_device_bvh_builder_bit_exact). An
 // LBVH is shallower in build time and worse in traversal cost than a SAH tree, so it is meant for meshes large enough
 // that the host build time matters (pt_world_set_device_bvh_threshold); the traversal kernels' LDS stack bounds the
-// depth a tree may have, and a tree that comes out deeper is rejected (the caller falls back to the host builder).
+// depth a tree may have, and the builder keeps every tree inside the bound it is given (it no longer falls back).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -58,83 +58,66 @@ __global__ void k_keys(const TriD* tris, uint32_t n, Box64 mesh, Box64* tri_box,
     vals[i] = i;
 }
 
-// common-prefix length of the keys at sorted positions i and j; equal keys are told apart by the position itself
-__device__ inline int delta(const uint64_t* keys, int n, int i, int j) {
-    if (j < 0 || j >= n) return -1;
-    const uint64_t a = keys[i], b = keys[j];
-    if (a != b) return __clzll((long long)(a ^ b));
-    return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
-}
-
-// Karras 2012, one thread per internal node i in [0, n-1): its key range and its two children
-__global__ void k_hierarchy(const uint64_t* keys, int n, uint32_t* child /* 2 per node */, uint32_t* parent_node /* n-1 */, uint32_t* parent_leaf /* n */,
-                            uint32_t* range /* first, last per node */) {
-    const int i = (int)(blockIdx.x * BT + threadIdx.x);
-    if (i >= n - 1) return;
-    const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
-    const int dmin = delta(keys, n, i, i - d);
-    int lmax = 2;
-    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
-    int l = 0;
-    for (int t = lmax / 2; t >= 1; t /= 2)
-        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-    const int j = i + l * d;
-    const int dnode = delta(keys, n, i, j);
-    int s = 0;
-    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
-        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-        if (t == 1) break;
-    }
-    const int gamma = i + s * d + (d < 0 ? -1 : 0);
-    const int first = i < j ? i : j, last = i < j ? j : i;
-    const uint32_t left = first == gamma ? ((uint32_t)gamma | LEAF_BIT) : (uint32_t)gamma;
-    const uint32_t right = last == gamma + 1 ? ((uint32_t)(gamma + 1) | LEAF_BIT) : (uint32_t)(gamma + 1);
-    child[2 * i] = left;
-    child[2 * i + 1] = right;
-    range[2 * i] = (uint32_t)first;
-    range[2 * i + 1] = (uint32_t)last;
-    if (left & LEAF_BIT) parent_leaf[gamma] = (uint32_t)i; else parent_node[gamma] = (uint32_t)i;
-    if (right & LEAF_BIT) parent_leaf[gamma + 1] = (uint32_t)i; else parent_node[gamma + 1] = (uint32_t)i;
-}
-
+// ---- [r3] depth-bounded top-down build over the sorted codes -------------------------------------------------------------------
+// Round 2 built Karras' radix tree (one thread per internal node) — whose depth is whatever the codes make it: 30-45 levels for a
+// million triangles, far beyond the traversal kernels' LDS stacks (16-24 entries), so every mesh the builder exists for fell back
+// to the host. The same tree can be grown top-down, one LEVEL per launch: a node covering the sorted range [first, last] splits
+// where the highest differing bit of its first and last code flips (exactly the radix tree's split; equal codes: the middle), and
+// the split position is kept inside the window in which neither side exceeds what the levels still available below it can hold
+// (leaf_max << levels). Where the bound does not bind the topology IS the radix tree's; where it binds the cut moves to the
+// coarsest Morton-cell boundary inside the window (k_split_level) — a subtree is always a contiguous run of the sorted triangles. Nodes are
+// numbered in creation order, so every level is a contiguous id range and the boxes are fitted by walking the levels back up.
 __device__ inline Box64 merge(const Box64& a, const Box64& b) {
     Box64 r;
     for (int k = 0; k < 3; ++k) { r.lo[k] = fmin(a.lo[k], b.lo[k]); r.hi[k] = fmax(a.hi[k], b.hi[k]); }
     return r;
 }
-
-// bottom-up fit: the second thread to arrive at a node owns it (its sibling's box is visible behind the fence + atomic).
-// Also counts, per leaf, the internal ancestors that SURVIVE the collapse (range longer than leaf_max): the tree's depth.
-__global__ void k_fit(const Box64* tri_box, const uint32_t* vals, int n, const uint32_t* child, const uint32_t* parent_node, const uint32_t* parent_leaf,
-                      const uint32_t* range, uint32_t leaf_max, Box64* node_box, uint32_t* arrived, uint32_t* max_depth) {
-    const int i = (int)(blockIdx.x * BT + threadIdx.x);
-    if (i >= n) return;
-    uint32_t depth = 0;
-    for (uint32_t p = parent_leaf[i];;) {   // depth of this leaf's collapsed leaf = kept ancestors
-        if (range[2 * p + 1] - range[2 * p] + 1 > leaf_max) ++depth;
-        if (p == 0) break;
-        p = parent_node[p];
+// one level: every node of [level_first, level_end) picks its split and creates its children (leaves are only references)
+__global__ void k_split_level(const uint64_t* keys, uint32_t level_first, uint32_t level_end, uint32_t leaf_max, unsigned long long child_cap,
+                              uint32_t median_below, uint32_t* node_first, uint32_t* node_last, uint32_t* child, uint32_t* n_nodes) {
+    const uint32_t id = level_first + blockIdx.x * BT + threadIdx.x;
+    if (id >= level_end) return;
+    const uint32_t f = node_first[id], l = node_last[id];
+    const unsigned long long n = (unsigned long long)l - f + 1ull;              // > leaf_max: only internal nodes are created
+    // the radix-tree split of a run [a, b] of sorted codes: the last position whose code still agrees with keys[a] in the highest bit
+    // in which keys[a] and keys[b] differ (equal codes, or a run the caller wants halved: the middle)
+    auto radix_split = [&](uint32_t a, uint32_t b, bool halve) -> uint32_t {
+        const uint64_t ka = keys[a], kb = keys[b];
+        if (ka == kb || halve) return a + (b - a - 1u) / 2u;
+        const int prefix = __clzll((long long)(ka ^ kb));
+        uint32_t lo = a, hi = b;                                                 // keys[lo] shares more than `prefix` bits with ka, keys[hi] does not
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            const uint64_t x = ka ^ keys[mid];
+            if (x == 0ull || __clzll((long long)x) > prefix) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    uint32_t s = radix_split(f, l, n <= (unsigned long long)median_below);       // last position of the left child
+    // depth bound: both sides must fit into the levels below (child_cap triangles each); n <= 2 child_cap holds by induction.
+    // When the radix split violates it, the cut moves to the COARSEST Morton-cell boundary inside the admissible window of
+    // positions — the radix split of the window's own run — instead of to the window's edge: a cut through the middle of a cell
+    // gives two overlapping boxes (measured: clamping to the edge, or halving runs, costs 25-70 % of K2 on a 1.3 M-triangle mesh).
+    const unsigned long long nl = (unsigned long long)s - f + 1ull;
+    if (nl > child_cap || n - nl > child_cap) {
+        const uint32_t s_min = n > child_cap ? f + (uint32_t)(n - child_cap) - 1u : f;          // smallest admissible last-left position
+        const uint32_t s_max = child_cap < n - 1ull ? f + (uint32_t)child_cap - 1u : l - 1u;   // largest
+        s = s_min >= s_max ? s_min : radix_split(s_min, s_max + 1u, false);
+        if (s > s_max) s = s_max;
     }
-    atomicMax(max_depth, depth);
-    uint32_t node = parent_leaf[i];
-    for (;;) {
-        __threadfence();
-        if (atomicAdd(&arrived[node], 1u) == 0u) return;       // first arrival: the sibling subtree is not done yet
-        __threadfence();
-        const uint32_t l = child[2 * node], r = child[2 * node + 1];
-        const Box64 bl = (l & LEAF_BIT) ? tri_box[vals[l & ~LEAF_BIT]] : node_box[l];
-        const Box64 br = (r & LEAF_BIT) ? tri_box[vals[r & ~LEAF_BIT]] : node_box[r];
-        node_box[node] = merge(bl, br);
-        if (node == 0) return;
-        node = parent_node[node];
+    const uint32_t cf[2] = {f, s + 1u}, cl[2] = {s, l};
+    for (int c = 0; c < 2; ++c) {
+        const uint32_t cnt = cl[c] - cf[c] + 1u;
+        if (cnt <= leaf_max) {
+            child[2 * id + c] = REF_TRIS | ((cnt - 1u) << 27) | cf[c];
+        } else {
+            const uint32_t nid = atomicAdd(n_nodes, 1u);
+            node_first[nid] = cf[c];
+            node_last[nid] = cl[c];
+            child[2 * id + c] = REF_NODE | nid;
+        }
     }
 }
-
-__global__ void k_flags(const uint32_t* range, int n, uint32_t leaf_max, uint32_t* keep) {
-    const int i = (int)(blockIdx.x * BT + threadIdx.x);
-    if (i < n - 1) keep[i] = (range[2 * i + 1] - range[2 * i] + 1 > leaf_max) ? 1u : 0u;
-}
-
 // conservative f32 box of a padded f64 box: Builder::store_box of pt_scene.cpp
 __device__ inline void store_box(const Box64& b, float* lo, float* hi) {
     double m = 1e-3;
@@ -145,32 +128,29 @@ __device__ inline void store_box(const Box64& b, float* lo, float* hi) {
         hi[k] = __double2float_ru(b.hi[k] + pad);
     }
 }
-
-// kept internal nodes -> BvhNode records; a child whose range has <= leaf_max triangles becomes a triangle leaf
-__global__ void k_emit(const uint32_t* child, const uint32_t* range, const uint32_t* keep, const uint32_t* slot, const Box64* node_box,
-                       const Box64* tri_box, const uint32_t* vals, int n, BvhNode* out) {
-    const int i = (int)(blockIdx.x * BT + threadIdx.x);
-    if (i >= n - 1 || !keep[i]) return;
+// boxes of one level (the deeper levels are done): child boxes into the BvhNode record, their union kept for the parent
+__global__ void k_fit_level(const uint32_t* child, uint32_t level_first, uint32_t level_end, const Box64* tri_box, const uint32_t* vals, Box64* node_box,
+                            BvhNode* out) {
+    const uint32_t id = level_first + blockIdx.x * BT + threadIdx.x;
+    if (id >= level_end) return;
     BvhNode nd;
-    uint32_t ref[2];
+    Box64 bc[2];
     for (int c = 0; c < 2; ++c) {
-        const uint32_t ch = child[2 * i + c];
-        Box64 b;
-        if (ch & LEAF_BIT) {
-            const uint32_t pos = ch & ~LEAF_BIT;
-            b = tri_box[vals[pos]];
-            ref[c] = REF_TRIS | pos;                                              // one triangle (count - 1 = 0)
+        const uint32_t ref = child[2 * id + c];
+        if ((ref & REF_TYPE_MASK) == REF_TRIS) {
+            const uint32_t first = ref & 0x07FFFFFFu, count = ((ref >> 27) & 7u) + 1u;
+            bc[c] = tri_box[vals[first]];
+            for (uint32_t k = 1; k < count; ++k) bc[c] = merge(bc[c], tri_box[vals[first + k]]);
         } else {
-            b = node_box[ch];
-            if (keep[ch]) ref[c] = REF_NODE | slot[ch];
-            else ref[c] = REF_TRIS | ((range[2 * ch + 1] - range[2 * ch]) << 27) | range[2 * ch];
+            bc[c] = node_box[ref & 0x3FFFFFFFu];
         }
-        store_box(b, c == 0 ? nd.lo0 : nd.lo1, c == 0 ? nd.hi0 : nd.hi1);
+        store_box(bc[c], c == 0 ? nd.lo0 : nd.lo1, c == 0 ? nd.hi0 : nd.hi1);
     }
-    nd.child0 = ref[0];
-    nd.child1 = ref[1];
+    node_box[id] = merge(bc[0], bc[1]);
+    nd.child0 = child[2 * id];
+    nd.child1 = child[2 * id + 1];
     nd.pad0 = nd.pad1 = 0;
-    out[slot[i]] = nd;
+    out[id] = nd;
 }
 
 template <class T>
@@ -183,51 +163,58 @@ struct DevBuf {
 }  // namespace
 
 bool build_blas_device(const TriD* host_tris, uint32_t n, const double mesh_lo[3], const double mesh_hi[3], uint32_t leaf_max, uint32_t max_depth,
-                       DeviceBlas& out, hipStream_t st) {
+                       uint32_t median_below, DeviceBlas& out, hipStream_t st) {
     out.nodes.clear();
     out.order.clear();
     out.depth = 0;
-    if (n <= leaf_max || n < 2 || n > 0x07FFFFFFu) return false;   // a single leaf: nothing to build
+    if (n <= leaf_max || n < 2 || n > 0x07FFFFFFu || leaf_max < 1 || leaf_max > 8 || max_depth < 1 || max_depth > 40) return false;   // a single leaf: nothing to build
+    if (((unsigned long long)leaf_max << max_depth) < (unsigned long long)n) return false;      // cannot fit into max_depth levels at all
     DevBuf<TriD> tris;
     DevBuf<Box64> tri_box, node_box;
     DevBuf<uint64_t> keys, keys_sorted;
-    DevBuf<uint32_t> vals, vals_sorted, child, parent_node, parent_leaf, range, arrived, keep, slot, depth;
+    DevBuf<uint32_t> vals, vals_sorted, child, node_first, node_last, counter;
     DevBuf<BvhNode> nodes;
     DevBuf<char> tmp;
     if (!tris.alloc(n) || !tri_box.alloc(n) || !node_box.alloc(n) || !keys.alloc(n) || !keys_sorted.alloc(n) || !vals.alloc(n) || !vals_sorted.alloc(n) ||
-        !child.alloc(2 * (size_t)n) || !parent_node.alloc(n) || !parent_leaf.alloc(n) || !range.alloc(2 * (size_t)n) || !arrived.alloc(n) || !keep.alloc(n) ||
-        !slot.alloc(n) || !depth.alloc(1) || !nodes.alloc(n))
+        !child.alloc(2 * (size_t)n) || !node_first.alloc(n) || !node_last.alloc(n) || !counter.alloc(1) || !nodes.alloc(n))
         return false;
     Box64 mesh;
     for (int k = 0; k < 3; ++k) { mesh.lo[k] = mesh_lo[k]; mesh.hi[k] = mesh_hi[k]; }
     const dim3 grid((n + BT - 1) / BT), block(BT);
-    bool ok = hipMemcpyAsync(tris.p, host_tris, (size_t)n * sizeof(TriD), hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = ok && hipMemsetAsync(arrived.p, 0, (size_t)n * sizeof(uint32_t), st) == hipSuccess && hipMemsetAsync(depth.p, 0, sizeof(uint32_t), st) == hipSuccess;
-    if (!ok) return false;
+    if (hipMemcpyAsync(tris.p, host_tris, (size_t)n * sizeof(TriD), hipMemcpyHostToDevice, st) != hipSuccess) return false;
     hipLaunchKernelGGL(k_keys, grid, block, 0, st, tris.p, n, mesh, tri_box.p, keys.p, vals.p);
-    size_t tmp_bytes = 0, scan_bytes = 0;
+    size_t tmp_bytes = 0;
     if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st) != hipSuccess) return false;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep.p, slot.p, (int)n - 1, st) != hipSuccess) return false;
-    if (!tmp.alloc(std::max(tmp_bytes, scan_bytes))) return false;
+    if (!tmp.alloc(tmp_bytes)) return false;
     if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st) != hipSuccess) return false;
-    hipLaunchKernelGGL(k_hierarchy, grid, block, 0, st, keys_sorted.p, (int)n, child.p, parent_node.p, parent_leaf.p, range.p);
-    hipLaunchKernelGGL(k_fit, grid, block, 0, st, tri_box.p, vals_sorted.p, (int)n, child.p, parent_node.p, parent_leaf.p, range.p, leaf_max, node_box.p,
-                       arrived.p, depth.p);
-    hipLaunchKernelGGL(k_flags, grid, block, 0, st, range.p, (int)n, leaf_max, keep.p);
-    if (hipcub::DeviceScan::ExclusiveSum(tmp.p, scan_bytes, keep.p, slot.p, (int)n - 1, st) != hipSuccess) return false;
-    hipLaunchKernelGGL(k_emit, grid, block, 0, st, child.p, range.p, keep.p, slot.p, node_box.p, tri_box.p, vals_sorted.p, (int)n, nodes.p);
-    uint32_t h_depth = 0, last_keep = 0, last_slot = 0;
-    ok = hipMemcpyAsync(&h_depth, depth.p, sizeof h_depth, hipMemcpyDeviceToHost, st) == hipSuccess &&
-         hipMemcpyAsync(&last_keep, keep.p + (n - 2), sizeof last_keep, hipMemcpyDeviceToHost, st) == hipSuccess &&
-         hipMemcpyAsync(&last_slot, slot.p + (n - 2), sizeof last_slot, hipMemcpyDeviceToHost, st) == hipSuccess &&
-         hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+    // root = node 0 over the whole sorted range; then one launch per level (a host round trip each: <= max_depth of them)
+    const uint32_t root_range[2] = {0u, n - 1u}, one = 1u;
+    bool ok = hipMemcpyAsync(node_first.p, &root_range[0], sizeof(uint32_t), hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(node_last.p, &root_range[1], sizeof(uint32_t), hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(counter.p, &one, sizeof(uint32_t), hipMemcpyHostToDevice, st) == hipSuccess;
     if (!ok) return false;
-    const uint32_t n_nodes = last_slot + last_keep;
-    out.depth = (int)h_depth;
-    if (n_nodes == 0 || h_depth > max_depth) return false;        // too deep for the traversal stacks: the caller builds on the host
-    out.nodes.resize(n_nodes);
+    std::vector<uint32_t> level_start{0u};          // level L = node ids [level_start[L], level_start[L + 1])
+    uint32_t created = 1;
+    for (uint32_t level = 0; level_start.back() < created; ++level) {
+        if (level >= max_depth) return false;                                   // (cannot happen: the clamp keeps every subtree inside its budget)
+        const uint32_t first = level_start.back(), end = created;
+        level_start.push_back(end);
+        const unsigned long long child_cap = (unsigned long long)leaf_max << (max_depth - level - 1u);   // what a child's subtree may hold
+        hipLaunchKernelGGL(k_split_level, dim3((end - first + BT - 1) / BT), block, 0, st, keys_sorted.p, first, end, leaf_max, child_cap, median_below, node_first.p,
+                           node_last.p, child.p, counter.p);
+        if (hipMemcpyAsync(&created, counter.p, sizeof created, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
+        if (created > n) return false;
+    }
+    const uint32_t n_levels = (uint32_t)level_start.size() - 1u;               // level_start = {0, .., created}
+    for (uint32_t level = n_levels; level-- > 0;) {
+        const uint32_t first = level_start[level], end = level_start[level + 1];
+        hipLaunchKernelGGL(k_fit_level, dim3((end - first + BT - 1) / BT), block, 0, st, child.p, first, end, tri_box.p, vals_sorted.p, node_box.p, nodes.p);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return false;
+    out.depth = (int)n_levels;          // depth of the deepest leaf (root = 0), counted like the host builder's depth_reached
+    out.nodes.resize(created);
     out.order.resize(n);
-    ok = hipMemcpy(out.nodes.data(), nodes.p, (size_t)n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost) == hipSuccess &&
+    ok = hipMemcpy(out.nodes.data(), nodes.p, (size_t)created * sizeof(BvhNode), hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(out.order.data(), vals_sorted.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
     return ok;
 }

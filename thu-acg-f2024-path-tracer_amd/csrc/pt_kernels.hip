@@ -1474,6 +1474,8 @@ static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min 
     case 163: return k_extend2<16, 3>;
     case 164: return k_extend2<16, 4>;
     case 204: return k_extend2<20, 4>;
+    case 283: return k_extend2<28, 3>;   // deep trees (the GPU builder's LBVHs of million-triangle meshes): 47.5 / 51.5 KB of LDS per block,
+    case 323: return k_extend2<32, 3>;   // still three blocks per CU (160 KB)
     default: return k_extend2<24, 3>;   // 24 stack entries: 43.5 KB of LDS per block, three blocks per CU
     }
 }

@@ -304,14 +304,14 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     // the instantiation. extend_code: -1 = batch, -(stack*10 + blocks) = two-phase.
     auto extend2_code = [&]() -> int {
         const int need = (int)s->stack_need_extend2;
-        if (need > 24) return 0;
+        if (need > 32) return 0;
         // four blocks per CU where the LDS allows it (stacks of 16 and 20 entries): the kernel then runs at 128 registers with
         // 64 B of spills per lane and is still 7.5 % faster than at three blocks and 149 registers (round 2; in round 1, at
         // 166 registers, the same bound meant 168 B of spills and lost 11 %)
-        int code = need <= 16 ? 164 : need <= 20 ? 204 : 243;
+        int code = need <= 16 ? 164 : need <= 20 ? 204 : need <= 24 ? 243 : need <= 28 ? 283 : 323;
         if (const char* e = exp_env("PT_EXT2")) {
             const int c = atoi(e);
-            if (c / 10 >= need && (c == 163 || c == 164 || c == 204 || c == 243)) code = c;
+            if (c / 10 >= need && (c == 163 || c == 164 || c == 204 || c == 243 || c == 283 || c == 323)) code = c;
         }
         return code;
     };

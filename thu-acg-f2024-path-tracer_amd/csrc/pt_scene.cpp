@@ -605,10 +605,20 @@ int pt::scene_build(pt_scene* s) {
                 Box bb = sb.local;
                 bool on_device = false;
                 if (s->device_bvh_min_tris != 0 && o->tris.size() >= s->device_bvh_min_tris) {
-                    // large mesh: LBVH on the GPU (pt_bvh_device.hip); a tree too deep for the traversal stacks falls back
+                    // large mesh: depth-bounded LBVH on the GPU (pt_bvh_device.hip); only a HIP failure falls back to the host builder
                     DeviceBlas db;
                     const double lo[3] = {sb.local.lo.x, sb.local.lo.y, sb.local.lo.z}, hi[3] = {sb.local.hi.x, sb.local.hi.y, sb.local.hi.z};
-                    if (build_blas_device(o->tris.data(), (uint32_t)o->tris.size(), lo, hi, (uint32_t)leaf_max, (uint32_t)MAX_BLAS_DEPTH, db, s->ctx->stream)) {
+                    // depth budget: eight levels above a perfectly balanced tree — the radix tree of 1.3 M triangles comes out 27 deep, and
+                    // every level the bound takes away bends Morton splits (measured on that mesh, K2 per launch: 27 levels 1.78 ms,
+                    // 23: 1.83, 21: 2.19, 20: 2.50; the host's SAH tree 1.50) — within what the traversal stacks cover (k_extend2's
+                    // largest LDS stack holds 32 entries; TRAVERSAL_STACK bounds top level + mesh tree)
+                    int bal = 0;
+                    for (size_t cap = (size_t)leaf_max; cap < o->tris.size(); cap *= 2) ++bal;
+                    int dev_depth = std::min(29, std::max((int)MAX_BLAS_DEPTH, bal + 8));
+                    if (const char* ev = exp_env("PT_LBVH_DEPTH")) dev_depth = std::min(29, std::max(bal, atoi(ev)));
+                    uint32_t median_below = 0;
+                    if (const char* ev = exp_env("PT_LBVH_MEDIAN")) median_below = (uint32_t)atoi(ev);
+                    if (build_blas_device(o->tris.data(), (uint32_t)o->tris.size(), lo, hi, (uint32_t)leaf_max, (uint32_t)dev_depth, median_below, db, s->ctx->stream)) {
                         const uint32_t node_base = (uint32_t)nodes.size();
                         auto fix = [&](uint32_t ref) {
                             if ((ref & REF_TYPE_MASK) == REF_NODE) return REF_NODE | (node_base + ref);
