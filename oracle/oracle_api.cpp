@@ -312,9 +312,9 @@ extern "C" int orc_load_obj(const char* path, float** pos, uint32_t* n_pos, uint
     *pos = (float*)malloc(P.size() * sizeof(float) + 4);
     *idx = (uint32_t*)malloc(I.size() * sizeof(uint32_t) + 4);
     *uv = (float*)malloc(T.size() * sizeof(float) + 4);
-    memcpy(*pos, P.data(), P.size() * sizeof(float));
-    memcpy(*idx, I.data(), I.size() * sizeof(uint32_t));
-    memcpy(*uv, T.data(), T.size() * sizeof(float));
+    if (!P.empty()) memcpy(*pos, P.data(), P.size() * sizeof(float));     // (an empty vector's data() may be null: UB for memcpy even with n = 0)
+    if (!I.empty()) memcpy(*idx, I.data(), I.size() * sizeof(uint32_t));
+    if (!T.empty()) memcpy(*uv, T.data(), T.size() * sizeof(float));
     return 0;
 }
 

@@ -14,7 +14,7 @@ from typing import Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # ORACLE_LIB: the sanitizer build (make -C oracle asan)
 ASSET_DIR = os.path.join(os.path.dirname(_HERE), "assets")
 
 
