@@ -155,6 +155,23 @@ PT_DEV bool slab_f32(const float* lo, const float* hi, const RayF& f, float t_mi
     t_near = tn;
     return tn <= tf;
 }
+// Cuboid face culling (flat top level). `f` = the OBJECT-space ray reduced like any other (make_rayf with the box's extent), lo / hi =
+// the cuboid's object-space box. A face's exact f64 quad test (quad.rs:40-59) can only accept a hit with t in [t_min, t_best] at
+// a point of the box's surface, and such a point satisfies, for every axis, t_near_axis <= t <= t_far_axis. With the proven
+// slab bound |t' - t| <= e per axis (above): the face on plane b of axis a stays a candidate iff t'_b + e_a >= max over the
+// axes of (near' - e) and t'_b - e_a <= min over the axes of (far' + e) — the ray's ENTRY and EXIT faces, plus whatever the margin
+// cannot tell apart at an edge. Bits follow pt_cuboid's face order (cuboid.rs:18-52): 0 +z front, 1 +x right, 2 -z back,
+// 3 -x left, 4 +y top, 5 -y bottom. Conservative only: which hit wins is still decided by the f64 tests of the faces kept.
+PT_DEV uint32_t cuboid_face_mask(const float* lo, const float* hi, const RayF& f, float t_min, float t_max) {
+    const float lx = __builtin_fmaf(lo[0], f.idx, -f.oix), hx = __builtin_fmaf(hi[0], f.idx, -f.oix);
+    const float ly = __builtin_fmaf(lo[1], f.idy, -f.oiy), hy = __builtin_fmaf(hi[1], f.idy, -f.oiy);
+    const float lz = __builtin_fmaf(lo[2], f.idz, -f.oiz), hz = __builtin_fmaf(hi[2], f.idz, -f.oiz);
+    const float tn = fmaxf(fmaxf(fminf(lx, hx) - f.ex, fminf(ly, hy) - f.ey), fmaxf(fminf(lz, hz) - f.ez, t_min));
+    const float tf = fminf(fminf(fmaxf(lx, hx) + f.ex, fmaxf(ly, hy) + f.ey), fminf(fmaxf(lz, hz) + f.ez, t_max));
+    if (!(tn <= tf)) return 0u;
+    auto cand = [&](float t, float e) -> uint32_t { return (t + e >= tn && t - e <= tf) ? 1u : 0u; };
+    return cand(hz, f.ez) | (cand(hx, f.ex) << 1) | (cand(lz, f.ez) << 2) | (cand(lx, f.ex) << 3) | (cand(hy, f.ey) << 4) | (cand(ly, f.ey) << 5);
+}
 // one BVH2 node: both children tested, near-first order; returns the number of children to visit
 PT_DEV int visit_node(const BvhNode* nd, const RayF& f, float t_min, float t_max, uint32_t& first, uint32_t& second) {
     const float4 q0 = ((const float4*)nd)[0], q1 = ((const float4*)nd)[1], q2 = ((const float4*)nd)[2];
@@ -345,6 +362,9 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
 #ifndef PT_FLAT_DIRECT
 #define PT_FLAT_DIRECT 1            // 0: on-the-spot tests look the primitive up in prims[] (A/B)
 #endif
+#ifndef PT_CUBOID_CULL
+#define PT_CUBOID_CULL 1            // 0: all six faces of a cuboid are tested (A/B)
+#endif
 #ifndef PT_PAIR_SINGLE
 #define PT_PAIR_SINGLE 1            // 0: only cuboids (six faces behind one transform) go through the pair passes
 #endif
@@ -401,7 +421,8 @@ PT_PAIR_PASS_ATTR void pair_pass(const SceneD& sc, const RayD& r, double t_min, 
 // Must be called by whole waves (`alive` = false for lanes without a ray). on_mesh(ei, entry, best): a lane's ray entered the
 // box of mesh entry `ei` (wave-uniform index).
 // PAIRS: cuboids few rays of the chunk enter go through the pair passes (L must be valid); false: everything on the spot.
-template <bool PAIRS, class OnMesh>
+// CULL: compile the cuboid face culling in (the instantiation for scenes without cuboids leaves it out: its registers spilled there).
+template <bool PAIRS, bool CULL, class OnMesh>
 PT_DEV Closest flat_top_level(const SceneD& sc, bool alive, const RayD& r, const RayF& f, double t_min, float t_min_f, int lane, const PairLds& L,
                               OnMesh&& on_mesh) {
     if constexpr (PAIRS) {
@@ -442,6 +463,26 @@ PT_DEV Closest flat_top_level(const SceneD& sc, bool alive, const RayD& r, const
         if (!PAIRS || (!PT_PAIR_SINGLE && n_faces == 1u) || cnt >= (uint32_t)PT_PAIR_DENSE_MIN) {
             // a box many rays of the chunk enter: the test on the spot, with the primitive's record in scalar registers, is
             // cheaper than that many pairs — and its hits trim the boxes that follow
+            if (CULL && PT_CUBOID_CULL && bx.kind == ENTRY_CUBOID && bx.prim_kind == PRIM_QUAD) {
+                // the six faces behind one transform: only those the object-space ray can enter or leave through are tested, and
+                // a face no lane of the chunk needs costs neither its 128-byte record nor its test (cuboid_face_mask)
+                RayD lr{};
+                uint32_t fm = 0u;
+                if (hb) {
+                    lr = ray_to_local_chain<true>(sc, bx.inst, r);
+                    const CuboidBox cb = ldu(&sc.cuboid_box[k]);
+                    fm = cuboid_face_mask(cb.lo, cb.hi, make_rayf(lr.o, lr.d, bx.extent), t_min_f, t_max_f);
+                }
+                for (uint32_t fi = 0; fi < 6u; ++fi) {
+                    const bool need = (fm >> fi) & 1u;
+                    if (__ballot(need) == 0ull) continue;
+                    const QuadD qd = ldu(&sc.quads[bx.prim_index + fi]);
+                    double t, a, b;
+                    if (need && hit_quad(qd, lr, t_min, t, a, b)) consider(best, t, bx.first_prim + fi);
+                }
+                t_max_f = t_max_f32(best.t);
+                continue;
+            }
             if (hb) {
                 const RayD lr = ray_to_local_chain<true>(sc, bx.inst, r);
                 if (PT_FLAT_DIRECT && bx.prim_kind == PRIM_SPHERE) {
@@ -463,10 +504,22 @@ PT_DEV Closest flat_top_level(const SceneD& sc, bool alive, const RayD& r, const
             continue;
         }
         if constexpr (PAIRS) {
-            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            uint32_t fm = 0x3Fu;                                         // faces this lane's ray may hit (all, when not culled)
+            if (CULL && PT_CUBOID_CULL && bx.kind == ENTRY_CUBOID && bx.prim_kind == PRIM_QUAD) {
+                fm = 0u;
+                if (hb) {
+                    const RayD lr = ray_to_local_chain<true>(sc, bx.inst, r);
+                    const CuboidBox cb = ldu(&sc.cuboid_box[k]);
+                    fm = cuboid_face_mask(cb.lo, cb.hi, make_rayf(lr.o, lr.d, bx.extent), t_min_f, t_max_f);
+                }
+            }
             for (uint32_t fi = 0; fi < n_faces; ++fi) {
-                if (hb) ((volatile uint32_t*)L.pairs)[(tail + rank) % PAIR_CAP] = ((bx.first_prim + fi) << 6) | (uint32_t)lane;
-                tail += cnt;
+                const bool need = hb && ((fm >> fi) & 1u);
+                const unsigned long long mf = __ballot(need);
+                if (mf == 0ull) continue;
+                const uint32_t rank = (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
+                if (need) ((volatile uint32_t*)L.pairs)[(tail + rank) % PAIR_CAP] = ((bx.first_prim + fi) << 6) | (uint32_t)lane;
+                tail += (uint32_t)__popcll(mf);
                 if (tail - head >= 64u) {
                     pair_pass(sc, r, t_min, lane, L, head, 64u);
                     head += 64u;
@@ -481,7 +534,7 @@ template <bool PAIRS>
 PT_DEV Closest closest_hit_flat(const SceneD& sc, bool alive, const RayD& r, double t_min, uint32_t* stk, int lane, const PairLds& L) {
     const float t_min_f = __double2float_rd(t_min);
     const RayF f = make_rayf(r.o, r.d, sc.tlas_extent);
-    return flat_top_level<PAIRS>(sc, alive, r, f, t_min, t_min_f, lane, L,
+    return flat_top_level<PAIRS, PAIRS>(sc, alive, r, f, t_min, t_min_f, lane, L,   // (the batch kernel's instantiation without pair passes serves scenes without cuboids)
                                 [&](uint32_t, const Entry& e, Closest& best) { blas_pass(sc, r, e, t_min, t_min_f, stk, TRAVERSAL_STACK, best); });
 }
 
@@ -678,7 +731,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
             if (sc.tlas_flat) {
                 // Small top level: the wave walks the ENTRY LIST together instead of each lane walking the tree
                 // (flat_top_level; the pair passes are left to the batch kernel: measured slower here, scene 6).
-                best = flat_top_level<false>(sc, alive, r, f, t_min, t_min_f, lane, PairLds{}, [&](uint32_t ei, const Entry& e, Closest& b) {
+                best = flat_top_level<false, true>(sc, alive, r, f, t_min, t_min_f, lane, PairLds{}, [&](uint32_t ei, const Entry& e, Closest& b) {
                     best = b;                                       // visit_entry works on this frame's `best`
                     visit_entry(std::true_type{}, ei, e, 0);
                     b = best;

@@ -728,6 +728,7 @@ int pt::scene_build(pt_scene* s) {
             m.rough_v = tex[m.rough_tex].v[0];
         }
     }
+    std::vector<CuboidBox> cuboid_box;
     std::vector<EntryBox> entry_box;   // tlas_items[i] is entry i (built in entry order, before the builder permutes them)
     for (int pass = 0; pass < 2; ++pass)   // spheres / quads / cuboids first: their hits trim the mesh boxes
         for (size_t i = 0; i < entry_boxes.size(); ++i) {
@@ -755,6 +756,14 @@ int pt::scene_build(pt_scene* s) {
                     eb.prim_index = p0.index;
                 }
             }
+            CuboidBox cb{};
+            if (e.kind == ENTRY_CUBOID && eb.prim_kind == PRIM_QUAD) {   // object-space box of the six faces (they are consecutive QuadD records)
+                Box local;
+                for (uint32_t k = 0; k < 6; ++k) local.grow(quad_box(quads[eb.prim_index + k]));
+                Builder::store_box(local, cb.lo, cb.hi);
+                eb.extent = box_extent(local);
+            }
+            cuboid_box.push_back(cb);
             entry_box.push_back(eb);
         }
     SceneD v{};
@@ -762,7 +771,7 @@ int pt::scene_build(pt_scene* s) {
     bool ok = upload(dev, nodes, v.nodes) && upload(dev, entries, v.entries) && upload(dev, prims, v.prims) &&
               upload(dev, spheres, v.spheres) && upload(dev, quads, v.quads) && upload(dev, tris, v.tris) &&
               upload(dev, tri_gid, v.tri_gid) && upload(dev, insts, v.insts) && upload(dev, tex, v.tex) &&
-              upload(dev, mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, atlas_f, v.atlas_f) && upload(dev, lights, v.lights) && upload(dev, entry_box, v.entry_box);
+              upload(dev, mats, v.mats) && upload(dev, atlas, v.atlas) && upload(dev, atlas_f, v.atlas_f) && upload(dev, lights, v.lights) && upload(dev, entry_box, v.entry_box) && upload(dev, cuboid_box, v.cuboid_box);
     if (ok && any_attr) ok = upload(dev, tri_attr, v.tri_attr);
     if (!ok) {
         dev.release();

@@ -71,6 +71,14 @@ struct EntryBox {
     uint32_t pad;
 };
 constexpr uint32_t ENTRYBOX_VIA_PRIMREF = 0xFFFFFFFFu;
+// Parallel to SceneD::entry_box, meaningful for ENTRY_CUBOID records: the cuboid's OBJECT-space box (cuboid.rs:11-58 builds its six
+// quads on the faces of [min, max]), f32 rounded outward like every stored box; EntryBox::extent then holds max |coordinate| of
+// it. The flat walk slab-tests the object-space ray against it and only runs the exact quad tests of the faces the ray can
+// enter or leave through (flat_top_level, "face culling"): typically two of the six.
+struct CuboidBox {
+    float lo[3], hi[3];
+    float pad[2];
+};
 struct SphereD { double r, p1[3], p2[3]; };
 struct QuadD { double q[3], u[3], v[3], w[3], n[3], d; };
 struct TriD { double v0[3], v1[3], v2[3]; };
@@ -148,6 +156,7 @@ struct SceneD {
     uint32_t tlas_root;          // child reference of the top-level root
     float tlas_extent;           // max |coordinate| of the top-level BVH boxes
     uint32_t n_entries, n_prims, n_lights;
+    const CuboidBox* cuboid_box; // parallel to entry_box (cuboid records only)
     const EntryBox* entry_box;   // the flat top level's walk list: one record per entry, NON-MESH entries first (each group in entry order)
     uint32_t tlas_flat;          // n_entries <= TLAS_FLAT_MAX: K2 walks the entry list instead of the top-level tree
     uint32_t flat_pairs;         // tlas_flat and the scene has cuboids: the batch K2 runs its (ray, primitive) pair passes
