@@ -190,6 +190,22 @@ struct TexVals {
     V3 color;
     double rough;
 };
+// The shading frame of a bounce and the view vector in it. sample(), pdf() and eval() of the reference each rebuild the same
+// quaternion from the same normal and rotate the same -ray.direction (sampling.rs:8-16 via diffuse.rs / metal.rs / glass.rs /
+// principled.rs): k_shade forms them ONCE per bounce for the hit's material (make_local_frame) — same inputs, same bits — and the
+// sampler and the pdf/eval code below take them from here (LF = true). The children of a MixBxDf build their own (LF = false).
+struct LocalFrame {
+    Frame f;
+    V3 v;
+};
+PT_DEV LocalFrame make_local_frame(const MatD& m, const HitD& h, V3 wo) {
+    LocalFrame lf{};
+    const uint32_t k = m.kind;
+    if (k == MAT_MIX || k == MAT_LIGHT) return lf;
+    lf.f = frame_to_z((k == MAT_PRINCIPLED || k == MAT_SHEEN) ? h.gn : h.sn);    // principled.rs / sheen.rs use the geometric normal
+    if (k != MAT_DIFFUSE) lf.v = to_local(lf.f, wo);                              // (Lambert needs no view vector)
+    return lf;
+}
 PT_DEV TexVals fetch_tex(const SceneD& sc, const MatD& m, const HitD& h) {
     TexVals tv{V3{0.0, 0.0, 0.0}, 0.0};
     const uint32_t k = m.kind;
@@ -201,24 +217,26 @@ PT_DEV TexVals fetch_tex(const SceneD& sc, const MatD& m, const HitD& h) {
 
 // ---- BxDFMaterial::sample (bsdf/mod.rs:23) ----------------------------------------------
 // wo = -ray.direction. Returns false where the reference returns None.
-PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, Rng& rng, double two_pi_scale, const TexVals& tv, V3& dir) {
+PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, Rng& rng, double two_pi_scale, const TexVals& tv, const LocalFrame& lf, V3& dir) {
     const MatD* leaf = &mat;
     double rough = tv.rough;
+    const bool own = mat.kind == MAT_MIX;   // a mix's child builds its own frame; everything else uses the bounce's (make_local_frame)
     if (mat.kind == MAT_MIX) {   // mix.rs:25-32: the selector is drawn first, then the chosen child samples
         double p = rng_f64(rng);
         leaf = &sc.mats[mat.p[0] < p ? mat.color_tex : mat.rough_tex];
         if (leaf->kind == MAT_METAL || leaf->kind == MAT_GLASS) rough = tex_f(sc, leaf->rough_tex, h.point);
     }
     const MatD& m = *leaf;
+    LocalFrame cf = lf;
+    if (own) cf = make_local_frame(m, h, wo);
+    const Frame f = cf.f;
+    const V3 v = cf.v;
     switch (m.kind) {
     case MAT_DIFFUSE: {   // diffuse.rs:51-54
-        Frame f = frame_to_z(h.sn);
         dir = to_world(f, cosine_sample_hemisphere(rng, two_pi_scale));
         return true;
     }
     case MAT_METAL: {     // metal.rs:39-54
-        Frame f = frame_to_z(h.sn);
-        V3 v = to_local(f, wo);
         V3 hv = ggx_sample_microfacet_normal(v, rough, rng);
         V3 d = to_world(f, reflect(-v, hv));
         if (dot(d, h.sn) <= 0.0) return false;
@@ -226,22 +244,18 @@ PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, 
         return true;
     }
     case MAT_GLASS: {     // glass.rs:66-90
-        Frame f = frame_to_z(h.sn);
-        V3 v = to_local(f, wo);
         V3 hv = ggx_sample_microfacet_normal(v, rough, rng);
         double eta_i = h.front ? 1.0 : m.ior, eta_o = h.front ? m.ior : 1.0;
         dir = to_world(f, sample_dielectric(v, hv, eta_i, eta_o, rng));
         return true;
     }
     case MAT_PRINCIPLED: {   // principled.rs:262-276 (lobe pick drawn before the lobe's own draws)
-        Frame f = frame_to_z(h.gn);
         double r = rng_f64(rng);
         const double p0 = m.lobe_p[0], p1 = m.lobe_p[1], p2 = m.lobe_p[2];
         if (r < p0) {
             dir = to_world(f, cosine_sample_hemisphere(rng, two_pi_scale));
             return true;
         }
-        V3 v = to_local(f, wo);
         const double roughness = m.p[1], ior = m.p[5];
         if (r < p0 + p1) {
             V3 hv = ggx_sample_microfacet_normal(v, roughness, rng);
@@ -263,13 +277,10 @@ PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, 
         return true;
     }
     case MAT_SHEEN: {     // sheen.rs:27-30
-        Frame f = frame_to_z(h.gn);
         dir = to_world(f, cosine_sample_hemisphere(rng, two_pi_scale));
         return true;
     }
     case MAT_CLEARCOAT: { // clearcoat.rs:23-35
-        Frame f = frame_to_z(h.sn);
-        V3 v = to_local(f, wo);
         V3 hv = gtr1_sample_microfacet_normal(0.25, rng);
         V3 d = to_world(f, reflect(-v, hv));
         if (dot(d, h.sn) <= 0.0) return false;
@@ -282,10 +293,11 @@ PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, 
 }
 
 // ---- BxDFMaterial::pdf + eval (cosine included in eval) -----------------------------------
-PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, const TexVals& tv, double& pdf, V3& brdf) {
+PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, const TexVals& tv, const LocalFrame& lf, double& pdf, V3& brdf) {
+    const Frame f = lf.f;     // the leaf's frame and local view vector (make_local_frame)
+    const V3 v = lf.v;
     switch (m.kind) {
     case MAT_DIFFUSE: {   // diffuse.rs:56-65
-        Frame f = frame_to_z(h.sn);
         V3 l = to_local(f, wi);
         V3 color = tv.color;
         pdf = fabs(l.z) / D_PI;
@@ -293,8 +305,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
         return;
     }
     case MAT_METAL: {     // metal.rs:56-80
-        Frame f = frame_to_z(h.sn);
-        V3 v = to_local(f, wo), l = to_local(f, wi);
+        V3 l = to_local(f, wi);
         V3 hv = normalize(v + l);
         double rough = tv.rough;
         V3 base = tv.color;
@@ -307,8 +318,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
         return;
     }
     case MAT_GLASS: {     // glass.rs:92-163
-        Frame f = frame_to_z(h.sn);
-        V3 v = to_local(f, wo), l = to_local(f, wi);
+        V3 l = to_local(f, wi);
         bool is_reflect = l.z * v.z > 0.0;
         double eta_i = h.front ? 1.0 : m.ior, eta_o = h.front ? m.ior : 1.0;
         V3 hv = generalized_half(v, l, is_reflect, eta_i, eta_o);
@@ -322,8 +332,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
         return;
     }
     case MAT_PRINCIPLED: {   // principled.rs:278-366, frame = geometric normal
-        Frame f = frame_to_z(h.gn);
-        V3 v = to_local(f, wo), l = to_local(f, wi);
+        V3 l = to_local(f, wi);
         bool is_reflect = l.z * v.z > 0.0;
         const double metallic = m.p[0], roughness = m.p[1], subsurface = m.p[2], specular = m.p[3],
                      specular_tint = m.p[4], ior = m.p[5], sheen = m.p[7], sheen_tint = m.p[8];
@@ -379,8 +388,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
         return;
     }
     case MAT_SHEEN: {     // sheen.rs:32-44
-        Frame f = frame_to_z(h.gn);
-        V3 v = to_local(f, wo), l = to_local(f, wi);
+        V3 l = to_local(f, wi);
         V3 hv = normalize(v + l);
         V3 c_sheen = vlerp(splat(1.0), tint(V3{m.p[0], m.p[1], m.p[2]}), m.p[3]);
         pdf = fabs(l.z) / D_PI;
@@ -388,8 +396,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
         return;
     }
     case MAT_CLEARCOAT: { // clearcoat.rs:37-60
-        Frame f = frame_to_z(h.sn);
-        V3 v = to_local(f, wo), l = to_local(f, wi);
+        V3 l = to_local(f, wi);
         V3 hv = normalize(v + l);
         double l_h = fabs(dot(l, hv));
         double dc = gtr1_D(l_h, m.alpha_g);
@@ -409,7 +416,7 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
 }
 // BxDFMaterial::pdf + eval incl. MixBxDf (mix.rs:34-44): (1-t)*child1 + t*child2. One non-unrolled loop
 // so that the leaf code above is instantiated once.
-PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, const TexVals& tv, double& pdf, V3& brdf) {
+PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, const TexVals& tv, const LocalFrame& lf, double& pdf, V3& brdf) {
     const bool mix = m.kind == MAT_MIX;
     const int n = mix ? 2 : 1;
     pdf = 0.0;
@@ -420,7 +427,8 @@ PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, 
         double pc;
         V3 fc;
         const TexVals ltv = mix ? fetch_tex(sc, lm, h) : tv;
-        leaf_pdf_eval(sc, lm, h, wo, wi, ltv, pc, fc);
+        const LocalFrame llf = mix ? make_local_frame(lm, h, wo) : lf;
+        leaf_pdf_eval(sc, lm, h, wo, wi, ltv, llf, pc, fc);
         if (!mix) {
             pdf = pc;
             brdf = fc;

@@ -1021,7 +1021,9 @@ struct NoPrefetch {
 //   D  regeneration (arithmetic), stores
 // vmcnt counts loads, stores, atomics and LDS-DMA in issue order, so a fetch can only hide behind a stretch in which no
 // younger load is waited for — hence the phase discipline (tex values fetched up front, pt_dev_bsdf.h fetch_tex).
-template <class Prefetch>
+// LIGHTS: the scene has a lights list (World::lights non-empty). The instantiation without compiles lights.sample / lights.pdf, the
+// selector draw and the later prefetch point out: p_light = 0 there (camera.rs:199-200), so no result changes.
+template <bool LIGHTS, class Prefetch>
 PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane, const SlotIn& in,
                        uint32_t& shard, uint32_t& n_done, uint32_t& n_died, Prefetch&& prefetch) {
     PT_STAMP(1);
@@ -1058,6 +1060,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     HitD hit{};
     const MatD* mp = nullptr;
     TexVals tv{};
+    LocalFrame lf{};
     PT_STAMP_VAR(a1);
     if (live) {
         if (!pool.dynamic) {
@@ -1075,6 +1078,7 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             is_hit = true;
             mp = &sc.mats[hit.mat];
             tv = fetch_tex(sc, *mp, hit);
+            lf = make_local_frame(*mp, hit, -ray.d);
             // camera.rs:186-187 — added for every material (zero unless emissive) so that a
             // non-finite throughput poisons the sample exactly as it does in the reference
             V3 emission = mp->kind == MAT_LIGHT ? tv.color : V3{0.0, 0.0, 0.0};
@@ -1084,9 +1088,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     PT_STAMP(a2);
     const bool any_hit = __ballot(is_hit) != 0ull;
     bool fetched = false;                                              // wave-uniform
-    if (any_hit && sc.n_lights == 0u) { prefetch(); fetched = true; }  // P1
+    if (any_hit && !LIGHTS) { prefetch(); fetched = true; }            // P1
     // ---- phase B1: roulette and the next direction ------------------------------------------------------------------------
-    const double p_light = sc.n_lights == 0 ? 0.0 : 0.5;               // :199-200
+    const double p_light = LIGHTS ? 0.5 : 0.0;                         // :199-200 (the host picks the instantiation by World::lights)
     const double p_bsdf = 1.0 - p_light;
     const V3 wo = -ray.d;
     V3 dir{};
@@ -1100,11 +1104,15 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
         if (!finished) {
             // :201 draws the selector even when there are no lights (p_light = 0: never below it) — then only the counter moves
             double rsel = 1.0;
-            if (sc.n_lights == 0u) ++rng.draw;
-            else rsel = rng_f64(rng);
             bool ok = true;
-            if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
-            else ok = mat_sample(sc, *mp, hit, wo, rng, cam.two_pi_scale, tv, dir);
+            if constexpr (LIGHTS) {
+                rsel = rng_f64(rng);
+                if (rsel < p_light) dir = lights_sample(sc, hit.point, ray.time, rng);
+                else ok = mat_sample(sc, *mp, hit, wo, rng, cam.two_pi_scale, tv, lf, dir);
+            } else {
+                ++rng.draw;
+                ok = mat_sample(sc, *mp, hit, wo, rng, cam.two_pi_scale, tv, lf, dir);
+            }
             if (!ok) finished = parked = true;                         // :209-211
             else have_dir = true;
         }
@@ -1115,8 +1123,9 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     if (have_dir) {
         double bsdf_pdf;
         V3 brdf;
-        mat_pdf_eval(sc, *mp, hit, wo, dir, tv, bsdf_pdf, brdf);
-        double light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
+        mat_pdf_eval(sc, *mp, hit, wo, dir, tv, lf, bsdf_pdf, brdf);
+        double light_pdf = 0.0;
+        if constexpr (LIGHTS) light_pdf = lights_pdf(sc, hit.point, dir, ray.time);
         double pdf = p_bsdf * bsdf_pdf + p_light * light_pdf;
         V3 attenuation = brdf / pdf;
         double e = 1e-3 * signum(dot(dir, hit.gn));                    // :217-222
@@ -1243,7 +1252,7 @@ static_assert(SORT_WINDOW <= 65536, "k_shade: s_perm holds 16-bit slot offsets")
 // same-class slots from an LDS cursor until the window is done — waves execute one material's code
 // instead of serialising through all of them, the expensive classes go first and are spread over all
 // waves of the block (work stealing), and every slot's records are moved whole by its own lane.
-template <bool SORT, int MINW>
+template <bool SORT, int MINW, bool LIGHTS>
 __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     uint32_t n_done = 0, n_died = 0;   // per thread and launch: far below 2^32 (64-bit counters here were the kernel's only spills)
     const int lane = (int)(threadIdx.x & 63u);
@@ -1259,7 +1268,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
         for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK) {
             const uint32_t s = base + threadIdx.x;
             const SlotIn in = load_slot_global(pool, s, true);
-            shade_slot(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, NoPrefetch{});
+            shade_slot<LIGHTS>(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, NoPrefetch{});
         }
     } else {
         __shared__ uint16_t s_perm[SORT_WINDOW];
@@ -1398,7 +1407,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                         staged_next = true;
                     }
                 };
-                shade_slot(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, prefetch);
+                shade_slot<LIGHTS>(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, prefetch);
 #ifdef PT_STAMPS
                 if (lane == 0) atomicAdd(&g_prof[N_CLASSES][4], 1ull);
 #endif
@@ -1541,19 +1550,19 @@ void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_
     else hipLaunchKernelGGL(pick_extend_batch(sc.tlas_flat, sc.flat_pairs), grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
 }
 typedef void (*shade_fn)(SceneD, CamD, PoolD, CountersD*, uint64_t);
-static shade_fn pick_shade(int variant) {   // variant = sort*10 + min waves per SIMD
+static shade_fn pick_shade(int variant, bool lights) {   // variant = sort*10 + min waves per SIMD
     switch (variant) {
-    case 2: return k_shade<false, 2>;
-    case 3: return k_shade<false, 3>;
-    case 12: return k_shade<true, 2>;
-    case 13: return k_shade<true, 3>;
-    default: return k_shade<false, 2>;
+    case 2: return lights ? k_shade<false, 2, true> : k_shade<false, 2, false>;
+    case 3: return lights ? k_shade<false, 3, true> : k_shade<false, 3, false>;
+    case 12: return lights ? k_shade<true, 2, true> : k_shade<true, 2, false>;
+    case 13: return lights ? k_shade<true, 3, true> : k_shade<true, 3, false>;
+    default: return lights ? k_shade<false, 2, true> : k_shade<false, 2, false>;
     }
 }
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
                   hipStream_t st) {
     const uint32_t units = variant >= 10 ? (pool.n_alloc / SORT_WINDOW) * BLOCK : pool.n_alloc;   // one block per window / chunk
-    hipLaunchKernelGGL(pick_shade(variant), grid_for(units, max_blocks), dim3(BLOCK), 0, st, sc, cam, pool, cnt, seed);
+    hipLaunchKernelGGL(pick_shade(variant, sc.n_lights != 0u), grid_for(units, max_blocks), dim3(BLOCK), 0, st, sc, cam, pool, cnt, seed);
 }
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);
@@ -1570,9 +1579,9 @@ void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out,
 void launch_math_probe(int which, const double* in, uint32_t n, double* out, hipStream_t st) {
     hipLaunchKernelGGL(k_math_probe, grid_for(n, 2048), dim3(BLOCK), 0, st, which, in, n, out);
 }
-int kernel_occupancy_blocks(int which, int variant) {
+int kernel_occupancy_blocks(int which, int variant, bool lights) {
     int nb = 0;
-    const void* f = which == 0 ? (variant <= -100 ? (const void*)pick_extend2(-variant) : (const void*)pick_extend_batch(variant <= -2, variant == -3)) : (const void*)pick_shade(variant);
+    const void* f = which == 0 ? (variant <= -100 ? (const void*)pick_extend2(-variant) : (const void*)pick_extend_batch(variant <= -2, variant == -3)) : (const void*)pick_shade(variant, lights);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

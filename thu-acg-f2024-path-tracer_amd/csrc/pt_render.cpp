@@ -320,7 +320,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (!strcmp(e, "batch")) extend_code = -1;
         else if (!strcmp(e, "twophase") && extend2_code() != 0) extend_code = -extend2_code();
     }
-    const int blocks_extend = kernel_occupancy_blocks(0, extend_code == -1 && s->dev.view.tlas_flat ? (s->dev.view.flat_pairs ? -3 : -2) : extend_code), blocks_shade = kernel_occupancy_blocks(1, shade_variant);
+    const int blocks_extend = kernel_occupancy_blocks(0, extend_code == -1 && s->dev.view.tlas_flat ? (s->dev.view.flat_pairs ? -3 : -2) : extend_code), blocks_shade = kernel_occupancy_blocks(1, shade_variant, s->dev.view.n_lights != 0u);
     const int grid_extend = ctx->n_cus * blocks_extend * mult, grid_shade = ctx->n_cus * blocks_shade * mult;
 
     pool.accum = d_accum;
