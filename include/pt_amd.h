@@ -121,9 +121,13 @@ int pt_load_obj_single_index(const char* path, float** pos, uint32_t* n_pos, uin
 int pt_load_hdr_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);
 int pt_load_hdr_rgbf32(const char* path, float** rgb, uint32_t* w, uint32_t* h);   /* the same decode without .to_rgb8(): f32 RGB, free with pt_free */
 int pt_load_png_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);   /* PNG -> RGB8 (alpha dropped like to_rgb8, texture.rs:67) */
+/* JPEG -> RGB8: baseline and progressive Huffman JPEG (the reference's earthmap.jpg / envmap.jpg, main.rs:100,365) with libjpeg's
+ * reference arithmetic (ISLOW integer IDCT, fixed-point YCbCr->RGB, fancy chroma upsampling): csrc/pt_jpeg.cpp */
+int pt_load_jpeg_rgb8(const char* path, uint8_t** rgb, uint32_t* w, uint32_t* h);
 void pt_free(void*);
-/* images this library does not decode (JPEG): hand them over decoded, under the file name
- * the reference's scene opens ("envmap.jpg", "earthmap.jpg", "bricks/color.png", ...) */
+/* images decoded by the caller (any format this library has no decoder for — or pixels a host wants to substitute): hand them
+ * over decoded, under the file name the reference's scene opens ("envmap.jpg", "earthmap.jpg", "bricks/color.png", ...); a
+ * registered image takes precedence over the file */
 int pt_register_image(pt_scene*, const char* name, uint32_t w, uint32_t h, const uint8_t* rgb);
 int pt_find_registered_image(pt_scene*, const char* name);   /* texture handle or -1 */
 int pt_save_png(const char* path, uint32_t w, uint32_t h, const uint8_t* rgb);   /* imgbuf.save camera.rs:118 */

@@ -143,6 +143,63 @@ def test_png_decoder_matches_pillow_and_roundtrips(pt, tmp_path):
         pt.load_png_rgb8(os.path.join(pt.ASSET_DIR, "earthmap.jpg"))
 
 
+def test_jpeg_decoder_matches_pillow(pt, tmp_path):
+    """pt_load_jpeg_rgb8 (csrc/pt_jpeg.cpp: Huffman baseline + progressive, ISLOW integer IDCT, libjpeg's fixed-point YCbCr->RGB,
+    fancy chroma upsampling) against Pillow (libjpeg-turbo), PIXEL FOR PIXEL: the reference's own JPEG assets — earthmap.jpg
+    (baseline, scene 2) and envmap.jpg (progressive, 7616x3808, scene 5) — and synthetic files over colour / grey, 4:4:4 / 4:2:2 /
+    4:2:0, sequential / progressive, two qualities, restart intervals and odd sizes. The reference itself decodes with zune-jpeg
+    0.4.13 (image 0.25.5), which is not available here: the decoder is pinned to libjpeg's arithmetic, "parity unpinned" against
+    zune-jpeg's (IDCT and upsampling implementations may differ in the last bit of a sample)."""
+    from PIL import Image
+
+    for n in ("earthmap.jpg", "envmap.jpg"):
+        path = os.path.join(pt.ASSET_DIR, n)
+        np.testing.assert_array_equal(pt.load_jpeg_rgb8(path), np.asarray(Image.open(path).convert("RGB")), err_msg=n)
+    rng = np.random.default_rng(3)
+
+    def picture(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 11.0), 128 + 90 * np.cos(x / 5.0 + y / 9.0), 60 + x * 150.0 / w], axis=2) + rng.normal(0, 12, (h, w, 3))
+        return np.clip(img, 0, 255).astype(np.uint8)
+    n_cases = 0
+    for h, w in ((64, 64), (37, 53), (1, 1), (8, 17), (120, 201)):
+        base = picture(h, w)
+        for mode in ("RGB", "L"):
+            im = Image.fromarray(base if mode == "RGB" else base[..., 0], mode)
+            for sub in ((0, 1, 2) if mode == "RGB" else (0,)):
+                for prog in (False, True):
+                    for q, rst in ((35, 0), (90, 3)):
+                        path = str(tmp_path / "t.jpg")
+                        kw = dict(quality=q, subsampling=sub, progressive=prog, optimize=(q == 90))
+                        if rst:
+                            kw["restart_marker_blocks"] = rst
+                        im.save(path, "JPEG", **kw)
+                        np.testing.assert_array_equal(pt.load_jpeg_rgb8(path), np.asarray(Image.open(path).convert("RGB")), err_msg=str(((h, w), mode, sub, prog, q, rst)))
+                        n_cases += 1
+    assert n_cases == 80
+    # damaged input is an error, never a crash: truncations and flipped bytes of the baseline asset
+    data = open(os.path.join(pt.ASSET_DIR, "earthmap.jpg"), "rb").read()
+    bad = str(tmp_path / "bad.jpg")
+    for k in (0, 1, 2, 100, 383, 400, len(data) // 2):
+        open(bad, "wb").write(data[:k])
+        try:
+            img = pt.load_jpeg_rgb8(bad)
+            assert img.shape == (512, 1024, 3)          # a cut inside the scan decodes what is there (libjpeg does too)
+        except pt.PtError:
+            pass
+    for _ in range(40):
+        b = bytearray(data)
+        for _ in range(4):
+            b[int(rng.integers(2, 600))] = int(rng.integers(0, 256))
+        open(bad, "wb").write(bytes(b))
+        try:
+            pt.load_jpeg_rgb8(bad)
+        except pt.PtError:
+            pass
+    with pytest.raises(pt.PtError, match="not a JPEG"):
+        pt.load_jpeg_rgb8(os.path.join(pt.ASSET_DIR, "bricks/color.png"))
+
+
 def test_obj_single_index_expansion(pt, tmp_path):
     """OBJ with vn and separate v/vt/vn streams: every distinct corner becomes one vertex, so the
     position-indexed attribute lookup of pt_mesh / mesh.rs:173-184 is right. Quads are fan-triangulated, negative indices

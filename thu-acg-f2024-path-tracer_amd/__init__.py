@@ -92,7 +92,7 @@ ABI_SYMBOLS = [
     "pt_sphere", "pt_quad", "pt_cuboid", "pt_mesh", "pt_instance",
     "pt_world_add_object", "pt_world_add_light", "pt_world_build", "pt_world_prim_count",
     "pt_world_set_device_bvh_threshold", "pt_world_device_bvh_info",
-    "pt_load_obj", "pt_load_obj_single_index", "pt_load_hdr_rgb8", "pt_load_hdr_rgbf32", "pt_load_png_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
+    "pt_load_obj", "pt_load_obj_single_index", "pt_load_hdr_rgb8", "pt_load_hdr_rgbf32", "pt_load_png_rgb8", "pt_load_jpeg_rgb8", "pt_free", "pt_register_image", "pt_find_registered_image", "pt_save_png",
     "pt_build_scene", "pt_camera_init", "pt_render", "pt_resolve_u8", "pt_intersect", "pt_math_probe",
     "pt_shard_range", "pt_comm_create", "pt_comm_destroy", "pt_comm_rank", "pt_comm_world", "pt_comm_barrier", "pt_comm_allreduce_f64",
     "pt_bootstrap_exchange", "pt_render_multi",
@@ -160,6 +160,8 @@ def _load():
     lib.pt_load_obj.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32)),
                                 C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32)]
     lib.pt_load_hdr_rgb8.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if hasattr(lib, "pt_load_jpeg_rgb8"):
+        lib.pt_load_jpeg_rgb8.argtypes = lib.pt_load_hdr_rgb8.argtypes
     if hasattr(lib, "pt_load_png_rgb8"):
         lib.pt_load_png_rgb8.argtypes = lib.pt_load_hdr_rgb8.argtypes
         fp, up = C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32)
@@ -197,8 +199,9 @@ def _d3(v):
 
 
 def decode_image_rgb8(path: str) -> np.ndarray:
-    """JPEG/PNG -> RGB8 (H, W, 3) via Pillow (the role of image::ImageReader for formats the
-    C++ host does not decode; alpha is dropped like ``to_rgb8`` does, texture.rs:67)."""
+    """JPEG/PNG -> RGB8 (H, W, 3) via PILLOW — an independent decoder, kept for the tests (the oracle is fed these pixels, the
+    product decodes the same files itself: pt_load_jpeg_rgb8 / pt_load_png_rgb8) and for formats the library has no decoder
+    for (hand the result to Scene.register_image). Alpha is dropped like ``to_rgb8`` does, texture.rs:67."""
     from PIL import Image
 
     return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8))
@@ -356,13 +359,9 @@ class Scene:
         _check(lib.pt_register_image(self.handle, name.encode(), w, h, img.ctypes.data), "register_image")
 
     def build_scene(self, scene_id: int, width: int, spp: int, asset_dir: str = ASSET_DIR, scene_seed: int = 1) -> Camera:
-        """Run the reference's scene script N (main.rs `-s N`). JPEG/PNG assets the script
-        opens are decoded with Pillow and handed over first."""
-        for sid, names in _SCENE_IMAGES.items():
-            if sid == scene_id:
-                for n in names:
-                    if lib.pt_find_registered_image(self.handle, n.encode()) < 0:
-                        self.register_image(n, decode_image_rgb8(os.path.join(asset_dir, n)))
+        """Run the reference's scene script N (main.rs `-s N`). Every image the scripts open (.hdr, .png, .jpg) is decoded by the
+        library itself (pt_load_hdr_rgb8 / pt_load_png_rgb8 / pt_load_jpeg_rgb8); pixels handed over with register_image first
+        take precedence."""
         cam = Camera()
         _check(lib.pt_build_scene(self.handle, scene_id, width, spp, asset_dir.encode(), scene_seed, C.byref(cam)), "pt_build_scene")
         return cam
@@ -409,8 +408,6 @@ class Scene:
         return out
 
 
-# images each scene script opens that the C++ host cannot decode itself (JPEG / PNG)
-_SCENE_IMAGES = {2: ["earthmap.jpg"], 5: ["envmap.jpg"]}     # JPEG only: PNG (scene 7) and Radiance HDR are decoded by the library
 # every non-HDR image a scene script opens (for hosts that decode everything themselves, e.g. the test oracle via Pillow)
 SCENE_IMAGE_FILES = {2: ["earthmap.jpg"], 5: ["envmap.jpg"], 7: ["bricks/color.png", "bricks/normal.png"]}
 
@@ -452,6 +449,16 @@ def load_obj_single_index(path: str):
     for p in (pos, idx, nrm, uv):
         lib.pt_free(p)
     return out
+
+
+def load_jpeg_rgb8(path: str) -> np.ndarray:
+    """Baseline / progressive JPEG -> RGB8 by the library's own decoder (csrc/pt_jpeg.cpp)."""
+    p = C.POINTER(C.c_uint8)()
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib.pt_load_jpeg_rgb8(path.encode(), C.byref(p), C.byref(w), C.byref(h)), "pt_load_jpeg_rgb8")
+    img = np.ctypeslib.as_array(p, (h.value, w.value, 3)).copy()
+    lib.pt_free(p)
+    return img
 
 
 def load_png_rgb8(path: str) -> np.ndarray:

@@ -96,9 +96,9 @@ struct CheckerTexture : Texture<T> {
         return e.done[this] = h;
     }
 };
-// ImageTexture::new(filename) texture.rs:62-69. Decoding: .hdr and .png natively (pt_load_hdr_rgb8, pt_load_png_rgb8);
-// anything else (JPEG) must have been handed over decoded (pt_register_image, keyed by the path
-// relative to the asset directory) or sit next to the file as a "<file>.rgb8" sidecar
+// ImageTexture::new(filename) texture.rs:62-69. Decoding: .hdr, .png and .jpg natively (pt_load_hdr_rgb8, pt_load_png_rgb8, pt_load_jpeg_rgb8);
+// anything else must have been handed over decoded (pt_register_image, keyed by the path
+// relative to the asset directory; a registered image always wins) or sit next to the file as a "<file>.rgb8" sidecar
 // ("PTRGB8 <w> <h>\n" + w*h*3 bytes; tools/prepare_assets.py writes them with Pillow).
 struct ImageTexture : Texture<Vec3> {
     std::string filename;
@@ -464,6 +464,10 @@ inline int ImageTexture::emit(Emitter& e) const {
         pt_free(rgb);
     } else if (key.size() > 4 && key.substr(key.size() - 4) == ".png") {
         if (pt_load_png_rgb8(path.c_str(), &rgb, &w, &hh) != 0) panic("ImageTexture::new(" + filename + ")");
+        h = pt_tex_image_rgb8(e.scene, w, hh, rgb);
+        pt_free(rgb);
+    } else if ((key.size() > 4 && key.substr(key.size() - 4) == ".jpg") || (key.size() > 5 && key.substr(key.size() - 5) == ".jpeg")) {
+        if (pt_load_jpeg_rgb8(path.c_str(), &rgb, &w, &hh) != 0) panic("ImageTexture::new(" + filename + ")");
         h = pt_tex_image_rgb8(e.scene, w, hh, rgb);
         pt_free(rgb);
     } else {

@@ -10,7 +10,7 @@ import oracle_py as orc
 
 lib = C.CDLL(sys.argv[1])
 u8pp, f32pp, u32pp, u32p = C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)
-lib.pt_load_png_rgb8.argtypes = lib.pt_load_hdr_rgb8.argtypes = [C.c_char_p, u8pp, u32p, u32p]
+lib.pt_load_png_rgb8.argtypes = lib.pt_load_hdr_rgb8.argtypes = lib.pt_load_jpeg_rgb8.argtypes = [C.c_char_p, u8pp, u32p, u32p]
 lib.pt_load_hdr_rgbf32.argtypes = [C.c_char_p, f32pp, u32p, u32p]
 lib.pt_load_obj.argtypes = [C.c_char_p, f32pp, u32p, u32pp, u32p, f32pp, u32p]
 lib.pt_load_obj_single_index.argtypes = [C.c_char_p, f32pp, u32p, u32pp, u32p, f32pp, u32p, f32pp, u32p]
@@ -94,6 +94,17 @@ def main():
     for name in ("bricks/color.png",):
         data = open(os.path.join(A, name), "rb").read()
         for m in mutations(data, rng, n_trunc=6, n_flip=6): put(m); image(lib.pt_load_png_rgb8, path, C.POINTER(C.c_uint8))
+    # ---- JPEG: the reference's baseline asset and a small progressive 4:2:0 file with restart markers, mutated (header bytes hit hardest)
+    from PIL import Image
+    jp = os.path.join(tmp, "p.jpg")
+    Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8), "RGB").save(jp, "JPEG", quality=70, subsampling=2, progressive=True, restart_marker_blocks=2)
+    for src, n_t, n_f in ((os.path.join(A, "earthmap.jpg"), 12, 30), (jp, 40, 200)):
+        data = open(src, "rb").read()
+        for m in mutations(data, rng, n_trunc=n_t, n_flip=n_f): put(m); image(lib.pt_load_jpeg_rgb8, path, C.POINTER(C.c_uint8))
+        for _ in range(n_f):                                   # flips confined to the headers (tables, frame, scan parameters)
+            b = bytearray(data)
+            for _ in range(3): b[int(rng.integers(2, min(len(b), 700)))] = int(rng.integers(0, 256))
+            put(bytes(b)); image(lib.pt_load_jpeg_rgb8, path, C.POINTER(C.c_uint8))
     # ---- Radiance HDR: the reference's probe, mutated; hand-made bad runs and sizes
     data = open(os.path.join(A, "grace_probe_latlong.hdr"), "rb").read()
     for m in mutations(data, rng, n_trunc=10, n_flip=12):
