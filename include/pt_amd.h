@@ -87,7 +87,7 @@ int pt_mat_glass(pt_scene*, int color_tex, int rough_tex, double anisotropic, do
 int pt_mat_principled(pt_scene*, int color_tex, const double params[11]);   /* PrincipledBSDF::new principled.rs:45-73, same argument order */
 int pt_mat_light(pt_scene*, int emission_tex);                          /* DiffuseLight::new material.rs:155-164 */
 /* the three bsdf/ materials no reference scene instantiates */
-int pt_mat_mix(pt_scene*, double t, int mat1, int mat2);                /* MixBxDf::new mix.rs:14-20 (children must be non-mix) */
+int pt_mat_mix(pt_scene*, double t, int mat1, int mat2);                /* MixBxDf::new mix.rs:14-20; a child may itself be a mix of non-mix materials (two levels) */
 int pt_mat_sheen(pt_scene*, double r, double g, double b, double sheen_tint);   /* SheenBRDF::new sheen.rs:17-22 */
 int pt_mat_clearcoat(pt_scene*, double clearcoat_gloss);                /* ClearcoatBRDF::new clearcoat.rs:14-18 */
 /* ---- geometry: src/hittable/ ------------------------------------------------------------ */

@@ -148,7 +148,6 @@ extern "C" int orc_mat_principled(orc_scene* s, int color_tex, const double p[11
 extern "C" int orc_mat_mix(orc_scene* s, double t, int m1, int m2) {
     CHECK_MAT(s, m1);
     CHECK_MAT(s, m2);
-    if (dynamic_cast<MixBxDf*>(s->mats[m1].get()) || dynamic_cast<MixBxDf*>(s->mats[m2].get())) return fail("nested mix materials are not supported");
     auto m = std::make_shared<MixBxDf>();
     m->t = clampd(t, 0.0, 1.0);   // mix.rs:16
     m->a = s->mats[m1];

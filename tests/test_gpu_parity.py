@@ -404,11 +404,14 @@ def test_sheen_clearcoat_mix_bit_exact(pt, det, ctx):
     glass = spec.add("mat_glass", rgb(1.0, 1.0, 1.0), spec.add("tex_solid_f", 0.1), 0.0, 1.5)
     mixes = [spec.add("mat_mix", 0.3, diffuse, coat), spec.add("mat_mix", 0.5, prin, sheen),
              spec.add("mat_mix", 0.0, sheen, glass), spec.add("mat_mix", 1.0, coat, glass), spec.add("mat_mix", 0.8, sheen, coat)]
+    # MixBxDf::new takes any Arc<dyn BxDFMaterial> (mix.rs:14-20): a mix of a mix and a leaf, and a mix of two mixes — the selector
+    # is drawn once per level (mix.rs:25-32) and every level rounds its own weighted sum (mix.rs:34-44)
+    mixes += [spec.add("mat_mix", 0.4, mixes[1], glass), spec.add("mat_mix", 0.65, mixes[0], mixes[4])]
     spec.add("world_add_object", spec.add("quad", (-6.0, 0.0, -6.0), (0.0, 0.0, 12.0), (12.0, 0.0, 0.0), mixes[0]))
     mats = [sheen, coat] + mixes
     for i, m in enumerate(mats):
-        x = -3.0 + i
-        spec.add("world_add_object", spec.add("sphere", 0.45, (x, 0.45, 0.0), (x, 0.45, 0.0), m))
+        x = -3.6 + 0.9 * i
+        spec.add("world_add_object", spec.add("sphere", 0.4, (x, 0.4, 0.0), (x, 0.4, 0.0), m))
     P, I = icosphere(1)
     N = (P / np.linalg.norm(P, axis=1, keepdims=True)).astype(np.float32)
     mesh = spec.add("mesh", 0.8, P, I, N, None, mixes[4])
@@ -467,8 +470,9 @@ def test_error_behaviour(pt, ctx):
     m = s.mat_diffuse(s.tex_solid_rgb(1, 1, 1))
     with pytest.raises(pt.PtError, match="bad material"):
         s.mat_mix(0.5, m, 17)
-    with pytest.raises(pt.PtError, match="nested"):
-        s.mat_mix(0.5, s.mat_mix(0.5, m, s.mat_clearcoat(0.5)), m)
+    two = s.mat_mix(0.5, s.mat_mix(0.5, m, s.mat_clearcoat(0.5)), m)                   # a mix of a mix: fine (two levels)
+    with pytest.raises(pt.PtError, match="deeper than two"):
+        s.mat_mix(0.5, two, m)
     q = s.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
     s.world_add_object(q)
     s.world_add_object(q)                                           # the same Arc twice is legal (world.rs:18-24)

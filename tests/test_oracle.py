@@ -77,10 +77,13 @@ def test_kat_sheen_clearcoat_mix(orc):   # sheen.rs:32-44, clearcoat.rs:37-60, m
     assert ps == pytest.approx(p_sheen, rel=1e-14) and fs == pytest.approx(f_sheen, rel=1e-13)
     assert pc == pytest.approx(p_coat, rel=1e-13) and fc == pytest.approx(f_coat, rel=1e-13)
     assert pm == (1 - t) * ps + t * pc and np.array_equal(fm, (1 - t) * fs + t * fc)
-    # MixBxDf::new clamps t (mix.rs:16); nested mixes are rejected by this build
+    # MixBxDf::new clamps t (mix.rs:16)
     assert s.mat_probe(s.mat_mix(1.7, sheen, coat), n, v, l)[0] == 0.0 * ps + 1.0 * pc
-    with pytest.raises(Exception):
-        s.mat_mix(0.5, mix, coat)
+    # a child may be a mix itself (mix.rs:14-20 takes any Arc<dyn BxDFMaterial>): every level rounds its own two products and sum
+    t2 = 0.6
+    nested = s.mat_mix(t2, mix, coat)
+    pn, fn = s.mat_probe(nested, n, v, l)
+    assert pn == (1 - t2) * pm + t2 * pc and np.array_equal(fn, (1 - t2) * fm + t2 * fc)
     s.close()
 
 

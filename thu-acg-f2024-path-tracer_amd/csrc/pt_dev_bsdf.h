@@ -186,6 +186,7 @@ PT_DEV V3 sample_dielectric(V3 v, V3 h, double eta_i, double eta_o, Rng& rng) { 
 // up front: k_shade keeps every global-memory read of a bounce in its first phase so that the pure arithmetic that
 // follows — sample, pdf, eval, next ray — can hide the asynchronous fetch of the wave's next group of path records.
 // The reference looks the same textures up again in each of sample / pdf / eval with the same arguments: same values.
+constexpr int MIX_MAX_DEPTH = 2;     // levels of MixBxDf the host admits (pt_mat_mix): a mix of mixes of leaves
 struct TexVals {
     V3 color;
     double rough;
@@ -221,9 +222,12 @@ PT_DEV bool mat_sample(const SceneD& sc, const MatD& mat, const HitD& h, V3 wo, 
     const MatD* leaf = &mat;
     double rough = tv.rough;
     const bool own = mat.kind == MAT_MIX;   // a mix's child builds its own frame; everything else uses the bounce's (make_local_frame)
-    if (mat.kind == MAT_MIX) {   // mix.rs:25-32: the selector is drawn first, then the chosen child samples
-        double p = rng_f64(rng);
-        leaf = &sc.mats[mat.p[0] < p ? mat.color_tex : mat.rough_tex];
+    if (mat.kind == MAT_MIX) {   // mix.rs:25-32: the selector is drawn first, then the chosen child samples — which may be a mix again
+#pragma unroll 1
+        for (int depth = 0; depth < MIX_MAX_DEPTH && leaf->kind == MAT_MIX; ++depth) {
+            double p = rng_f64(rng);
+            leaf = &sc.mats[leaf->p[0] < p ? leaf->color_tex : leaf->rough_tex];
+        }
         if (leaf->kind == MAT_METAL || leaf->kind == MAT_GLASS) rough = tex_f(sc, leaf->rough_tex, h.point);
     }
     const MatD& m = *leaf;
@@ -414,31 +418,51 @@ PT_DEV void leaf_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo,
         return;
     }
 }
-// BxDFMaterial::pdf + eval incl. MixBxDf (mix.rs:34-44): (1-t)*child1 + t*child2. One non-unrolled loop
-// so that the leaf code above is instantiated once.
+// BxDFMaterial::pdf + eval incl. MixBxDf (mix.rs:34-44): (1-t)*child1 + t*child2, where a child may itself be a mix (MixBxDf::new takes
+// any Arc<dyn BxDFMaterial>, mix.rs:14-20) — the host admits MIX_MAX_DEPTH = 2 levels. The reference's recursion rounds every level's
+// two products and their sum separately, so the weights are NOT multiplied through: the (at most four) leaves are visited in
+// the recursion's order by ONE non-unrolled loop (the leaf code above is instantiated once), an inner accumulator holding the
+// current child's value while its second leaf is evaluated and an outer one holding the first child's weighted value.
 PT_DEV void mat_pdf_eval(const SceneD& sc, const MatD& m, const HitD& h, V3 wo, V3 wi, const TexVals& tv, const LocalFrame& lf, double& pdf, V3& brdf) {
     const bool mix = m.kind == MAT_MIX;
-    const int n = mix ? 2 : 1;
     pdf = 0.0;
     brdf = V3{0.0, 0.0, 0.0};
+    double cp = 0.0;                       // value of the child being evaluated
+    V3 cf{0.0, 0.0, 0.0};
+    const int n_leaves = mix ? 4 : 1;      // slots (child, grandchild); a leaf child uses one of its two
 #pragma unroll 1
-    for (int c = 0; c < n; ++c) {
-        const MatD& lm = mix ? sc.mats[c == 0 ? m.color_tex : m.rough_tex] : m;
-        double pc;
-        V3 fc;
+    for (int slot = 0; slot < n_leaves; ++slot) {
+        const int c = slot >> 1, g = slot & 1;
+        const MatD& child = mix ? sc.mats[c == 0 ? m.color_tex : m.rough_tex] : m;
+        const bool inner = mix && child.kind == MAT_MIX;
+        if (mix && !inner && g == 1) continue;                      // a leaf child has no second slot
+        const MatD& lm = inner ? sc.mats[g == 0 ? child.color_tex : child.rough_tex] : child;
+        double lp;
+        V3 lfv;
         const TexVals ltv = mix ? fetch_tex(sc, lm, h) : tv;
         const LocalFrame llf = mix ? make_local_frame(lm, h, wo) : lf;
-        leaf_pdf_eval(sc, lm, h, wo, wi, ltv, llf, pc, fc);
+        leaf_pdf_eval(sc, lm, h, wo, wi, ltv, llf, lp, lfv);
         if (!mix) {
-            pdf = pc;
-            brdf = fc;
-        } else {
-            const double w = c == 0 ? 1.0 - m.p[0] : m.p[0];
-            const double wp = w * pc;
-            const V3 wf = w * fc;
-            pdf = c == 0 ? wp : pdf + wp;
-            brdf = c == 0 ? wf : brdf + wf;
+            pdf = lp;
+            brdf = lfv;
+            break;
         }
+        if (inner) {                                                // mix.rs:34-44 one level down
+            const double wi_ = g == 0 ? 1.0 - child.p[0] : child.p[0];
+            const double wp = wi_ * lp;
+            const V3 wf = wi_ * lfv;
+            cp = g == 0 ? wp : cp + wp;
+            cf = g == 0 ? wf : cf + wf;
+            if (g == 0) continue;                                   // the child's second leaf comes next
+        } else {
+            cp = lp;
+            cf = lfv;
+        }
+        const double w = c == 0 ? 1.0 - m.p[0] : m.p[0];
+        const double wp = w * cp;
+        const V3 wf = w * cf;
+        pdf = c == 0 ? wp : pdf + wp;
+        brdf = c == 0 ? wf : brdf + wf;
     }
 }
 

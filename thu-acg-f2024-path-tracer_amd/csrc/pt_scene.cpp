@@ -166,7 +166,10 @@ extern "C" int pt_mat_principled(pt_scene* s, int color_tex, const double p[11])
 }
 extern "C" int pt_mat_mix(pt_scene* s, double t, int m1, int m2) {   // MixBxDf::new mix.rs:14-20
     if (!MAT_OK(s, m1) || !MAT_OK(s, m2)) return set_error("pt_mat_mix: bad material handle");
-    if (s->mats[m1].kind == MAT_MIX || s->mats[m2].kind == MAT_MIX) return set_error("pt_mat_mix: nested mix materials are not supported");
+    // a child may be a mix (MixBxDf::new takes any Arc<dyn BxDFMaterial>, mix.rs:14-20) — of leaves: the kernels evaluate two levels
+    for (int c : {m1, m2})
+        if (s->mats[c].kind == MAT_MIX && (s->mats[s->mats[c].color_tex].kind == MAT_MIX || s->mats[s->mats[c].rough_tex].kind == MAT_MIX))
+            return set_error("pt_mat_mix: MixBxDf nested deeper than two levels is not supported");
     MatD m = blank_mat(MAT_MIX);
     m.p[0] = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);   // t.clamp(0, 1)
     m.color_tex = m1;
