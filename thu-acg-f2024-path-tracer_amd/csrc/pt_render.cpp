@@ -219,10 +219,12 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     if (dynamic) {
         // Resident paths: enough that per-launch fixed costs and kernel tails amortise (16.8M slots are 9% faster than
         // 4.2M on the 4000-spp frame, 33.6M another 2%), few enough that the frame's end — when the sample budget is
-        // handed out and slots die — stays short: about 128 samples per slot, between 16K and 128K slots per CU
-        // (2.5 GB of path state at 16.8M).
+        // handed out and slots die — stays short: between 16K and 128K slots per CU (3.5 GB of path state at 33.6M).
+        // [r3] about 64 samples per slot (was 128; 32 gained another 5-15 % on scene 6 below 500 spp but lost 4 % on scene 5 at 4K): re-measured for the sample ranges ONE RANK of an 8-GPU frame renders — scene 6
+        // FHD @ 500 spp: 4.2 M slots 489 ms, 8.4 M (the old rule's choice) 426, 16.8 M 407.5, 33.6 M 409; @ 1000 spp: 8.4 M 846,
+        // 16.8 M (old) 785.5, 33.6 M 779 — the long, thin end of a frame costs less than running the whole frame on a small pool.
         uint64_t per_cu = 16384;   // a power of two (the tile-ordered work items and the 64 counter shards divide it evenly)
-        while (per_cu < 131072 && per_cu * 3 / 2 * (uint64_t)std::max(1, ctx->n_cus) * 128 <= total_work) per_cu *= 2;
+        while (per_cu < 131072 && per_cu * 3 / 2 * (uint64_t)std::max(1, ctx->n_cus) * 64 <= total_work) per_cu *= 2;
         uint64_t target = (uint64_t)ctx->n_cus * per_cu;
         if (const char* e = exp_env("PT_POOL_SLOTS")) {
             target = strtoull(e, nullptr, 10);
