@@ -55,6 +55,8 @@ typedef struct pt_render_stats {
     uint64_t launches_extend, launches_shade;
     uint32_t extend_variant, shade_variant;   /* K2: 0 two-phase k_extend2, 1 batch k_extend; K3: sort*10 + min waves/SIMD */
     uint32_t blocks_extend, blocks_shade;
+    uint32_t compactions;                  /* times the thinning pool was compacted at the frame's end (dynamic mode) */
+    uint32_t n_alloc_end;                  /* slots the last launches still covered */
 } pt_render_stats;
 
 const char* pt_last_error(void);

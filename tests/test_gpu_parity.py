@@ -685,6 +685,26 @@ def test_eight_rank_shards_into_one_device_accumulator_equal_the_full_render(pt,
     gs.close()
 
 
+def test_end_of_frame_pool_compaction_changes_no_result(pt, ctx):
+    """The thinning pool is compacted at the frame's end (k_compact_scan / k_compact_move): live slots move to the front and the
+    launches shrink. A frame whose whole budget fits the pool at once (one sample per slot: the render is nothing BUT its end) must
+    compact (at least once: the host acts on the live count of its last poll) and give the same sums as the static one-slot-per-pixel render, up to the order of the f64 additions;
+    counts are exact. Cornell box (lights list, deep paths: the longest tail) and scene 6 (meshes, two-phase K2)."""
+    for sid, width, spp in ((3, 160, 24), (6, 192, 20)):
+        gs = pt.Scene(ctx)
+        cam = gs.build_scene(sid, width, spp)
+        ref, st_ref = gs.render(cam, 5, 0, spp, slots_per_pixel=1)
+        dyn, st = gs.render(cam, 5, 0, spp)
+        assert st.compactions >= 1 and st.n_alloc_end < st.n_slots // 8, (st.compactions, st.n_alloc_end, st.n_slots)
+        assert st.samples == st_ref.samples and st.segments == st_ref.segments
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(dyn[fin], ref[fin], rtol=1e-11, atol=1e-11)
+        off, st_off = _with_env({"PT_EXPERIMENT": "1", "PT_NO_COMPACT_POOL": "1"}, lambda: gs.render(cam, 5, 0, spp))
+        assert st_off.compactions == 0 and st_off.segments == st.segments
+        np.testing.assert_allclose(off[fin], ref[fin], rtol=1e-11, atol=1e-11)
+        gs.close()
+
+
 def test_scene5_3840x2160_properties(pt, det, ctx, scene_images):
     """Config 5's frame size (scene 5, 3840x2160, the 87 MB environment atlas, a 199 MB accumulator) with 2 spp: shape,
     finiteness, counters, additivity of sample ranges, and ~100 random (pixel, sample)s bit-equal to the oracle's trace."""

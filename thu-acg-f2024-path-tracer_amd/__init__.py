@@ -77,6 +77,8 @@ class RenderStats(C.Structure):
         ("shade_variant", C.c_uint32),
         ("blocks_extend", C.c_uint32),
         ("blocks_shade", C.c_uint32),
+        ("compactions", C.c_uint32),
+        ("n_alloc_end", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -21,7 +21,7 @@ namespace pt {
 namespace {
 
 constexpr int BT = 256;
-constexpr uint32_t LEAF_BIT = 0x80000000u;
+
 
 struct Box64 {
     double lo[3], hi[3];

@@ -10,6 +10,8 @@ void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
                   hipStream_t st);
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st);
+// the frame's end (dynamic mode): live slots beyond new_end move into dead slots below it; holes / movers: scratch lists of `cap` entries, counts: 2 words
+void launch_compact(const PoolD& pool, uint32_t new_end, uint32_t* holes, uint32_t* movers, uint32_t* counts, uint32_t cap, int max_blocks, hipStream_t st);
 void launch_detile(const PoolD& pool, double* accum, int max_blocks, hipStream_t st);
 void launch_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8, hipStream_t st);
 void launch_probe(const SceneD& sc, const double* rays, uint32_t n, double* out, hipStream_t st);

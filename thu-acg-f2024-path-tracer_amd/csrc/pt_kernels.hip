@@ -1463,6 +1463,47 @@ __global__ __launch_bounds__(BLOCK) void k_detile(PoolD pool, double* accum) {
     }
 }
 
+// ---- the frame's END: compaction of the thinning pool (dynamic mode) -----------------------------------------------------------
+// When the sample budget is handed out the slots die one by one, and for the last ~60 iterations both kernels sweep a pool
+// that is mostly dead — every window pays its sort and its barriers for a handful of live paths (3-6 % of a frame on the pool
+// sizes one rank of a multi-GPU frame uses). The host, which polls the live count anyway, then moves the survivors to the
+// FRONT: the live slots beyond the new end L ("movers") go into the dead slots below it ("holes"), and every later launch covers
+// [0, L) only. k_compact_scan lists both kinds (one atomic per wave and list, any order); k_compact_move copies mover i's two
+// records and its state into hole i and marks the old slot dead. Which slot a path sits in decides nothing (the RNG is keyed by
+// pixel and sample, the frame accumulator by pixel): no result changes.
+__global__ __launch_bounds__(BLOCK) void k_compact_scan(PoolD pool, uint32_t new_end, uint32_t* holes, uint32_t* movers, uint32_t* counts /* [0] holes, [1] movers */,
+                                                        uint32_t cap) {
+    const int lane = (int)(threadIdx.x & 63u);
+    for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK) {   // n_alloc is a multiple of BLOCK: whole waves
+        const uint32_t s = base + threadIdx.x;
+        const bool dead = pool.bounce[s] == SLOT_DEAD;
+        const bool hole = s < new_end && dead, mover = s >= new_end && !dead;
+        for (int which = 0; which < 2; ++which) {
+            const unsigned long long m = __ballot(which == 0 ? hole : mover);
+            if (m == 0ull) continue;
+            uint32_t at = 0;
+            if (lane == __ffsll((long long)m) - 1) at = atomicAdd(&counts[which], (uint32_t)__popcll(m));
+            at = (uint32_t)__shfl((int)at, __ffsll((long long)m) - 1) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if ((which == 0 ? hole : mover) && at < cap) (which == 0 ? holes : movers)[at] = s;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_compact_move(PoolD pool, const uint32_t* holes, const uint32_t* movers, const uint32_t* counts, uint32_t cap) {
+    const uint32_t n = counts[1] < counts[0] ? counts[1] : counts[0];          // movers <= holes by construction (live slots <= new end)
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n && i < cap; i += gridDim.x * BLOCK) {
+        const uint32_t src = movers[i], dst = holes[i];
+        const u4v* r = reinterpret_cast<const u4v*>(&pool.ray[src]);
+        u4v* w = reinterpret_cast<u4v*>(&pool.ray[dst]);
+        const u4v a = r[0], b = r[1], c = r[2], d = r[3];
+        w[0] = a; w[1] = b; w[2] = c; w[3] = d;
+        const u4v* pr = reinterpret_cast<const u4v*>(&pool.path[src]);
+        u4v* pw = reinterpret_cast<u4v*>(&pool.path[dst]);
+        for (unsigned k = 0; k < sizeof(PathRec) / 16; ++k) pw[k] = pr[k];
+        pool.bounce[dst] = pool.bounce[src];
+        pool.bounce[src] = SLOT_DEAD;
+    }
+}
+
 // camera.rs:109-114,128-130: mean, sqrt gamma, clamp, truncate to u8
 __global__ __launch_bounds__(BLOCK) void k_quantise(const double* accum, uint32_t n, double scale, uint8_t* rgb8) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
@@ -1566,6 +1607,11 @@ void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, Counters
 }
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);
+}
+void launch_compact(const PoolD& pool, uint32_t new_end, uint32_t* holes, uint32_t* movers, uint32_t* counts, uint32_t cap, int max_blocks, hipStream_t st) {
+    (void)hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_compact_scan, grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, pool, new_end, holes, movers, counts, cap);
+    hipLaunchKernelGGL(k_compact_move, grid_for(cap, max_blocks), dim3(BLOCK), 0, st, pool, holes, movers, counts, cap);
 }
 void launch_detile(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_detile, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);

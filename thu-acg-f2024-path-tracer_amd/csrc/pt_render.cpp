@@ -365,6 +365,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const uint64_t per_slot = dynamic ? (total_work + n_slots - 1) / std::max<uint64_t>(n_slots, 1) + 1 : (spp + k - 1) / k;
     const uint64_t max_iterations = per_slot * ((uint64_t)std::max(1u, dc.max_depth) + 1) + 4;   // + 1: a parked slot idles one iteration
     uint32_t poll_every = 8;
+    const bool compact_ok = dynamic && !exp_env("PT_NO_COMPACT_POOL");
+    uint32_t compactions = 0;
     bool alive = spp != 0 && dc.max_depth != 0;
     if (spp != 0 && dc.max_depth == 0) {
         // max_depth = 0: trace() returns zero radiance for every sample (camera.rs:177); nothing to launch
@@ -383,9 +385,30 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (!hip_ok(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(CountersD), hipMemcpyDeviceToHost, st), "hipMemcpy(counters)")) return -1;
         if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize(render)")) return -1;
         timer.drain();
-        alive = s->h_counters->alive != 0;
+        const uint64_t n_alive = s->h_counters->alive;
+        alive = n_alive != 0;
         if (alive && iterations > max_iterations + 128) return set_error("pt_render: iteration bound exceeded (internal error)");
-        if (poll_every < 64) poll_every *= 2;
+        if (poll_every < 16) poll_every *= 2;     // (a poll is a pipeline drain of some tens of microseconds: every 16 iterations is <= 0.3 %)
+        // the frame's end: once three quarters of the pool are dead the survivors move to the front and the launches shrink with them
+        // (k_compact_scan / k_compact_move). The count is the last poll's — stale only towards MORE live slots, which errs on the safe side.
+        if (compact_ok && alive && n_alive * 4 <= pool.n_alloc && pool.n_alloc > 4 * 2048u) {
+            const uint32_t new_end = (uint32_t)((n_alive + 2047) & ~(uint64_t)2047);
+            const uint32_t cap = new_end;                                  // holes and movers are both at most the live count
+            const size_t words = 2 * (size_t)cap + 2;
+            if (words > s->compact_scratch_words) {
+                if (s->compact_scratch) (void)hipFree(s->compact_scratch);
+                s->compact_scratch = nullptr;
+                s->compact_scratch_words = 0;
+                if (!hip_ok(hipMalloc((void**)&s->compact_scratch, words * sizeof(uint32_t)), "hipMalloc(compaction lists)")) return -1;
+                s->compact_scratch_words = words;
+            }
+            timer.begin(2, st);
+            launch_compact(pool, new_end, s->compact_scratch, s->compact_scratch + cap, s->compact_scratch + 2 * (size_t)cap, cap, ctx->n_cus * 8, st);
+            timer.end(st);
+            pool.n_alloc = new_end;
+            pool.n_slots = std::min(pool.n_slots, new_end);
+            ++compactions;
+        }
     }
     if (!dynamic || tiled) {
         timer.begin(2, st);
@@ -443,6 +466,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         stats->shade_variant = (uint32_t)shade_variant;
         stats->blocks_extend = (uint32_t)grid_extend;
         stats->blocks_shade = (uint32_t)grid_shade;
+        stats->compactions = compactions;
+        stats->n_alloc_end = pool.n_alloc;
     }
     return 0;
 }

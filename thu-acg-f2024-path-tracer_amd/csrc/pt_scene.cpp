@@ -43,6 +43,7 @@ pt_scene::~pt_scene() {
     dev.release();
     if (pool_mem) (void)hipFree(pool_mem);
     if (tile_accum) (void)hipFree(tile_accum);
+    if (compact_scratch) (void)hipFree(compact_scratch);
     if (d_counters) (void)hipFree(d_counters);
     if (h_counters) (void)hipHostFree(h_counters);
 }

@@ -78,6 +78,8 @@ struct pt_scene {
     size_t pool_bytes = 0;
     double* tile_accum = nullptr;  // dynamic mode: the frame accumulator in tile order (PoolD::accum_tiled), re-used like the pool
     size_t tile_accum_bytes = 0;
+    uint32_t* compact_scratch = nullptr;   // the end-of-frame compaction's hole / mover lists + counters (pt_render.cpp)
+    size_t compact_scratch_words = 0;
     pt::CountersD* d_counters = nullptr;
     pt::CountersD* h_counters = nullptr;   // pinned
     ~pt_scene();
