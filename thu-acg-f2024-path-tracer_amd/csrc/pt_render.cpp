@@ -367,6 +367,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     uint32_t poll_every = 8;
     const bool compact_ok = dynamic && !exp_env("PT_NO_COMPACT_POOL");
     uint32_t compactions = 0;
+    uint64_t compact_num = 1, compact_den = 2;      // compact when live <= num/den of the slots still covered (25 % .. 85 % measured level: within 0.5 %)
+    uint32_t poll_cap = 8;
+    if (const char* e = exp_env("PT_COMPACT_AT")) { compact_num = (uint64_t)std::max(1, atoi(e)); compact_den = 100; }   // per cent
+    if (const char* e = exp_env("PT_POLL_CAP")) poll_cap = (uint32_t)std::max(1, atoi(e));
     bool alive = spp != 0 && dc.max_depth != 0;
     if (spp != 0 && dc.max_depth == 0) {
         // max_depth = 0: trace() returns zero radiance for every sample (camera.rs:177); nothing to launch
@@ -388,10 +392,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         const uint64_t n_alive = s->h_counters->alive;
         alive = n_alive != 0;
         if (alive && iterations > max_iterations + 128) return set_error("pt_render: iteration bound exceeded (internal error)");
-        if (poll_every < 16) poll_every *= 2;     // (a poll is a pipeline drain of some tens of microseconds: every 16 iterations is <= 0.3 %)
-        // the frame's end: once three quarters of the pool are dead the survivors move to the front and the launches shrink with them
+        if (poll_every < poll_cap) poll_every *= 2;     // (a poll is a pipeline drain of some tens of microseconds: every 8 iterations costs <= 0.5 %)
+        // the frame's end: once half of the slots still covered are dead the survivors move to the front and the launches shrink with them
         // (k_compact_scan / k_compact_move). The count is the last poll's — stale only towards MORE live slots, which errs on the safe side.
-        if (compact_ok && alive && n_alive * 4 <= pool.n_alloc && pool.n_alloc > 4 * 2048u) {
+        if (compact_ok && alive && n_alive * compact_den <= (uint64_t)pool.n_alloc * compact_num && pool.n_alloc > 4 * 2048u) {
             const uint32_t new_end = (uint32_t)((n_alive + 2047) & ~(uint64_t)2047);
             const uint32_t cap = new_end;                                  // holes and movers are both at most the live count
             const size_t words = 2 * (size_t)cap + 2;
