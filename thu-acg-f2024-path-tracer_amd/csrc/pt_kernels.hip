@@ -1024,8 +1024,11 @@ struct NoPrefetch {
 // LIGHTS: the scene has a lights list (World::lights non-empty). The instantiation without compiles lights.sample / lights.pdf, the
 // selector draw and the later prefetch point out: p_light = 0 there (camera.rs:199-200), so no result changes.
 template <bool LIGHTS, class Prefetch>
+// pre_mask / pre_base: the work items of this group's certain-to-end lanes were requested one group AHEAD (k_shade's prefetch point,
+// [r3]): pre_mask = those lanes, pre_base = the returning atomic's value in the mask's first lane. 0 = not requested: ask here.
 PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, uint32_t s, int lane, const SlotIn& in,
-                       uint32_t& shard, uint32_t& n_done, uint32_t& n_died, Prefetch&& prefetch) {
+                       uint32_t& shard, uint32_t& n_done, uint32_t& n_died, Prefetch&& prefetch, unsigned long long pre_mask = 0ull,
+                       unsigned long long pre_base = 0ull, uint32_t pre_shard = 0u) {
     PT_STAMP(1);
     uint32_t bounce = in.bounce;
     const bool alive = bounce != SLOT_DEAD;
@@ -1050,10 +1053,17 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
     // before anything is computed: their work items are requested NOW, so that the returning atomic's round trip to the work
     // counter (~3 k cycles, which only the SIMD's other wave could cover) runs under the environment lookup instead of in
     // front of the regeneration. Phase C consumes the answer; paths that end on a surface ask there, as before.
+    // [r3] One step further: the class of a wave's NEXT group is known a whole group ahead (the window's sorted result words), so
+    // k_shade requests these items at the previous group's prefetch point and hands the pending answer in (pre_mask, pre_base):
+    // the round trip — 3-4 us with every CU dequeuing — then runs under a whole group's work instead of under one environment lookup.
     unsigned long long early = 0ull, early_base = 0ull;
+    uint32_t early_shard = shard;
     if (pool.dynamic) {
         early = __ballot(alive && (was_idle || (in.hw >> HIT_CLASS_SHIFT) == CLASS_MISS));
-        if (early && lane == __ffsll((long long)early) - 1) early_base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(early));
+        early_shard = shard;
+        if (pre_mask != 0ull) { early_base = pre_base; early_shard = pre_shard; }   // (the same lanes by construction: both come from the slots' result words;
+                                                                                    //  the wave may have moved on to another shard since it asked)
+        else if (early && lane == __ffsll((long long)early) - 1) early_base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(early));
     }
     // ---- phase A: all global-memory reads of the bounce -------------------------------------------------------------
     bool is_hit = false;
@@ -1154,14 +1164,16 @@ PT_DEV void shade_slot(const SceneD& sc, const CamD& cam, const PoolD& pool, Cou
             const int leader = __ffsll((long long)need) - 1;
             const bool asking = (need >> lane) & 1ull;
             unsigned long long base = early_base;
+            uint32_t from = early_shard;                                              // the shard the answer in hand came from
             if (!have_base) {
                 base = 0;
+                from = shard;
                 if (lane == leader) base = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(need));
             }
             have_base = false;
             base = __shfl(base, leader);
             if (asking) {
-                const unsigned long long w = shard_item(base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull)), shard);
+                const unsigned long long w = shard_item(base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull)), from);
                 if (w < pool.total_work) {
                     more = true;
                     next_idle = !work_to_pixel(pool, w, next_pixel, next_sample, next_row, next_col);
@@ -1242,6 +1254,9 @@ static_assert((SORT_WINDOW / BLOCK) * 4 <= 32, "k_shade: the per-thread `keys` w
 static_assert(N_CLASSES <= 16, "k_shade: a class key is 4 bits wide (and the class field of K2's result word is bits 28..31)");
 static_assert(SORT_WINDOW % BLOCK == 0 && SORT_WINDOW / 64 == 32, "k_shade: one half-wave scans the 32 group counts of a class");
 static_assert(SORT_WINDOW <= 65536, "k_shade: s_perm holds 16-bit slot offsets");
+#ifndef PT_DEQUEUE_AHEAD
+#define PT_DEQUEUE_AHEAD 1          // 0: certain-to-end lanes request their work items at the start of their own group (the round-2 form)
+#endif
 #ifndef PT_K3_PREFETCH
 #define PT_K3_PREFETCH 1            // 0: every group's records straight from the pool (the round-1 form), for A/B
 #endif
@@ -1377,6 +1392,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             uint4* stage = s_stage[wave];
             uint32_t g = grab();
             bool staged = false;
+            unsigned long long pre_mask = 0ull, pre_base = 0ull;      // work items requested a group ahead (shade_slot)
+            uint32_t pre_shard = 0u;
             while (g < n_groups) {
                 PT_STAMP(0);
                 bool enable;
@@ -1396,6 +1413,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
 #endif
                 uint32_t g_next = n_groups;
                 bool staged_next = false;
+                unsigned long long pre_mask_next = 0ull, pre_base_next = 0ull;
+                uint32_t pre_shard_next = 0u;
                 auto prefetch = [&]() {
                     g_next = grab();
                     if (use_stage && g_next < n_groups) {
@@ -1405,9 +1424,20 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                         stage_fetch(pool, sn, stage, lane);
                         __builtin_amdgcn_sched_barrier(0);
                         staged_next = true;
+#if PT_DEQUEUE_AHEAD
+                        // the next group's lanes that are certain to end there (ray left the scene / idle slot): their work items now
+                        const uint32_t cn = s_hw[sn - wbase] >> HIT_CLASS_SHIFT;
+                        pre_mask_next = __ballot(en && (cn == CLASS_MISS || cn == CLASS_IDLE));
+                        pre_shard_next = shard;
+                        if (pre_mask_next && lane == __ffsll((long long)pre_mask_next) - 1)
+                            pre_base_next = atomicAdd(&cnt->work[shard].next, (unsigned long long)__popcll(pre_mask_next));
+#endif
                     }
                 };
-                shade_slot<LIGHTS>(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, prefetch);
+                shade_slot<LIGHTS>(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, prefetch, pre_mask, pre_base, pre_shard);
+                pre_mask = pre_mask_next;
+                pre_base = pre_base_next;
+                pre_shard = pre_shard_next;
 #ifdef PT_STAMPS
                 if (lane == 0) atomicAdd(&g_prof[N_CLASSES][4], 1ull);
 #endif
