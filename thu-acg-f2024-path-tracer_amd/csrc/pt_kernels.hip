@@ -1323,17 +1323,18 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             for (int j = 0; j < PER; ++j) {
                 const uint32_t key = (keys >> (4 * j)) & 15u;
                 rank[j] = 0;
-                for (uint32_t k = 0; k < NCLASS; ++k)
-                    if (lane == 0) s_cnt[k][j * (BLOCK / 64) + wave] = 0;
-                // only the classes present among the wave's 64 slots cost a ballot (typically two to four)
+                // only the classes present among the wave's 64 slots cost a ballot (typically two to four); lane k keeps class k's
+                // count and stores it — one LDS store per wave and chunk ([r3]; lane 0 used to zero eleven words and write the rest)
+                uint32_t mine = 0;
                 unsigned long long todo = ~0ull;
                 while (todo) {
                     const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)key, __ffsll((long long)todo) - 1));
                     const unsigned long long m = __ballot(key == k);
                     if (key == k) rank[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (lane == 0) s_cnt[k][j * (BLOCK / 64) + wave] = (uint32_t)__popcll(m);
+                    if ((uint32_t)lane == k) mine = (uint32_t)__popcll(m);
                     todo &= ~m;
                 }
+                if ((uint32_t)lane < NCLASS) s_cnt[lane][j * (BLOCK / 64) + wave] = mine;
             }
             __syncthreads();
             // exclusive prefix over the groups in slot order, per class: NGRP = 32 lanes scan one class with five shuffles (the
@@ -1353,18 +1354,16 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                 if (g == 31) s_hist[k] = incl;
             }
             __syncthreads();
-            uint32_t class_base[NCLASS];
-            {
-                uint32_t acc = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < NCLASS; ++k) { class_base[k] = acc; acc += s_hist[k]; }
-            }
+            // first position of every class: lane k of each wave sums the histogram below k (eleven LDS reads by eleven lanes)
+            // and the slots fetch theirs by a lane shuffle ([r3]; every thread used to build the table and select from it with
+            // eleven compares per slot)
+            uint32_t my_base = 0;
+            if ((uint32_t)lane < NCLASS)
+                for (uint32_t k = 0; k < (uint32_t)lane; ++k) my_base += s_hist[k];
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 const uint32_t key = (keys >> (4 * j)) & 15u;
-                uint32_t cb = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < NCLASS; ++k) cb = key == k ? class_base[k] : cb;
+                const uint32_t cb = (uint32_t)__shfl((int)my_base, (int)key);
                 const uint32_t pos = cb + s_cnt[key][j * (BLOCK / 64) + wave] + rank[j];
                 s_perm[pos] = (uint16_t)(j * BLOCK + threadIdx.x);
             }
