@@ -95,12 +95,16 @@ PT_DEV void tangent_basis(V3 n, V3& tangent, V3& bitangent) {
     bitangent = cross(n, tangent);
 }
 // HitInfo::new hit_info.rs:16-55
+// UM: `mat` is wave-uniform (lights.pdf walks the lights list in step): the material's normal-map handle arrives by a scalar load —
+// a vector load there would make the pure-arithmetic stretch of k_shade wait for the record prefetch it is meant to hide.
+template <bool UM = false>
 PT_DEV void finish_hit(const SceneD& sc, const RayD& r, V3 point, V3 normal, double dist, uint32_t mat, double u,
                        double v, HitD& h) {
     h.front = dot(r.d, normal) < 0.0;
     V3 nn = normalize(normal);
     h.gn = h.front ? nn : -nn;
-    int32_t nm = sc.mats[mat].nmap_tex;
+    int32_t nm;
+    if constexpr (UM) nm = ldu(&sc.mats[mat].nmap_tex); else nm = sc.mats[mat].nmap_tex;
     if (nm >= 0) {
         V3 m = 2.0 * tex_image(sc, sc.tex[nm], u, v) - splat(1.0);
         V3 t, b;
@@ -172,7 +176,9 @@ PT_DEV bool reconstruct_hit(const SceneD& sc, const RayD& world_ray, uint32_t gi
 // ---- lights list: Hittable::sample / pdf for every kind of object (list.rs:78-96, quad.rs:80-98,
 // sphere.rs:110-135, mesh.rs:122-141, cuboid.rs:78-84, instance.rs:64-75) ---------------------------
 PT_DEV V3 sample_quad_dir(const QuadD& q, V3 origin, Rng& rng) {                  // quad.rs:80-86
-    double a = rng_f64(rng), b = rng_f64(rng);
+    uint64_t ua, ub;
+    rng_u64x2(rng, ua, ub);                                                        // two consecutive draws: one Philox block when they share it
+    double a = u64_to_unit(ua), b = u64_to_unit(ub);
     V3 point = ld3(q.q) + ld3(q.u) * a + ld3(q.v) * b;
     return normalize(point - origin);
 }
@@ -181,25 +187,43 @@ PT_DEV double pdf_quad(const SceneD& sc, const QuadD& q, uint32_t mat, V3 origin
     double t, al, be;
     if (!hit_quad(q, r, 0.0, t, al, be)) return 0.0;
     HitD h;
-    finish_hit(sc, r, ray_at(r, t), ld3(q.n), t, mat, al, be, h);
+    finish_hit<true>(sc, r, ray_at(r, t), ld3(q.n), t, mat, al, be, h);   // (every caller hands a wave-uniform material: lights_pdf)
     double area = length(cross(ld3(q.u), ld3(q.v)));
     double cos_theta = fabs(dot(r.d, h.sn));
     return (h.dist * h.dist) / (cos_theta * area);
 }
-PT_DEV V3 lights_sample(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
+// ONE: the lights list has a single entry (the Cornell box, scene 7): the index draw still happens (list.rs:82 draws it), but the
+// light is the same for every lane, so its entry, transform chain and quad / sphere record arrive by scalar loads instead of four
+// DEPENDENT vector gathers (lights[i] -> entries -> prims -> quads, ~700 cycles each in k_shade).
+template <bool ONE>
+PT_DEV V3 lights_sample_impl(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
     uint32_t i = rng_index(rng, sc.n_lights);
-    const Entry e = sc.entries[sc.lights[i]];
+    Entry e;
+    if constexpr (ONE) e = ldu(&sc.entries[ldu(&sc.lights[0])]); else e = sc.entries[sc.lights[i]];
     V3 origin = origin_w;
     int32_t innermost = -1;
     for (int32_t k = e.inst; k >= 0;) {                                           // instance.rs:64-66, outermost instance first
-        const InstD& m = sc.insts[k];
-        origin = xform_point(m.i0, m.i1, m.i2, m.it, origin);
-        innermost = k;
-        k = m.inner;
+        if constexpr (ONE) {
+            const InstD m = ldu(&sc.insts[k]);
+            origin = xform_point(m.i0, m.i1, m.i2, m.it, origin);
+            innermost = k;
+            k = m.inner;
+        } else {
+            const InstD& m = sc.insts[k];
+            origin = xform_point(m.i0, m.i1, m.i2, m.it, origin);
+            innermost = k;
+            k = m.inner;
+        }
     }
     V3 dir;
     if (e.kind == ENTRY_QUAD) {
-        dir = sample_quad_dir(sc.quads[sc.prims[e.first_prim].index], origin, rng);
+        if constexpr (ONE) {
+            const PrimRef pr = ldu(&sc.prims[e.first_prim]);
+            const QuadD qd = ldu(&sc.quads[pr.index]);
+            dir = sample_quad_dir(qd, origin, rng);
+        } else {
+            dir = sample_quad_dir(sc.quads[sc.prims[e.first_prim].index], origin, rng);
+        }
     } else if (e.kind == ENTRY_CUBOID) {                                          // cuboid.rs:78-80 -> list.rs:78-84
         uint32_t j = rng_index(rng, 6u);
         dir = sample_quad_dir(sc.quads[sc.prims[e.first_prim + j].index], origin, rng);
@@ -227,6 +251,10 @@ PT_DEV V3 lights_sample(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
         k = m.outer;
     }
     return dir;
+}
+PT_DEV V3 lights_sample(const SceneD& sc, V3 origin_w, double time, Rng& rng) {
+    if (sc.n_lights == 1u) return lights_sample_impl<true>(sc, origin_w, time, rng);
+    return lights_sample_impl<false>(sc, origin_w, time, rng);
 }
 PT_DEV double lights_pdf(const SceneD& sc, V3 origin_w, V3 direction_w, double time) {
     if (sc.n_lights == 0) return 0.0;
