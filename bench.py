@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--slots-per-pixel", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last timed frame's f64 sum accumulator (H, W, 3) as .npy (tests)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="plumbing check without a GPU: every rank only runs the file rendezvous of pt_comm_create (pt_bootstrap_exchange) and rank 0 reports")
     return ap.parse_args()
@@ -275,6 +276,8 @@ def main():
             "roofline": roofline,
         }
         out["frame_check"] = frame_check(pt, ctx, args, acc, height)
+        if args.dump_frame:
+            np.save(args.dump_frame, acc)
         if world == 1 and not args.no_cpu_baseline:
             images = {n: pt.decode_image_rgb8(os.path.join(pt.ASSET_DIR, n)) for n in pt.SCENE_IMAGE_FILES.get(args.scene, [])}
             out["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.cpu_seconds, images)

@@ -705,6 +705,31 @@ def test_end_of_frame_pool_compaction_changes_no_result(pt, ctx):
         gs.close()
 
 
+def test_two_gpu_render_multi_equals_single_gpu(pt, ctx, tmp_path):
+    """pt_render_multi over TWO ranks (RCCL ncclReduce over xGMI) against the single-GPU frame — runs only where two GPUs are
+    visible (the 1-GPU boxes of this pool skip it; RCCL refuses two ranks on one device). `bench.py --gpus 2` starts its own two
+    ranks; rank 0's reduced frame must equal the one-rank frame up to the order of the f64 additions, and the JSON must say
+    n_gpus = 2 (the communicator's size)."""
+    import ctypes as C, json, subprocess, sys
+    hip = C.CDLL("libamdhip64.so")
+    n = C.c_int(0)
+    assert hip.hipGetDeviceCount(C.byref(n)) == 0
+    if n.value < 2:
+        pytest.skip(f"needs two GPUs ({n.value} visible): the world > 1 path of pt_render_multi stays unverified on hardware")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    frames = {}
+    for gpus in (1, 2):
+        out = str(tmp_path / f"f{gpus}.npy")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--width", "256", "--spp", "16", "--steps", "1", "--warmup", "0",
+                            "--no-cpu-baseline", "--dump-frame", out], capture_output=True, text=True, timeout=600,
+                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == gpus and line["frame_check"]["finite"]
+        frames[gpus] = np.load(out)
+    np.testing.assert_allclose(frames[2], frames[1], rtol=1e-12, atol=1e-12)
+
+
 def test_scene5_3840x2160_properties(pt, det, ctx, scene_images):
     """Config 5's frame size (scene 5, 3840x2160, the 87 MB environment atlas, a 199 MB accumulator) with 2 spp: shape,
     finiteness, counters, additivity of sample ranges, and ~100 random (pixel, sample)s bit-equal to the oracle's trace."""
