@@ -615,6 +615,9 @@ __shared__ unsigned long long g_prof[N_CLASSES + 1][PROF_COLS];
 #define PT_DRAIN()
 #endif
 
+#ifndef PT_K2_REVERSE
+#define PT_K2_REVERSE 1
+#endif
 #ifndef PT_K2_PREFETCH
 #define PT_K2_PREFETCH 0              // 1: phase A holds the next chunk's ray in registers while it walks the current one — the round-1 form,
 #endif                               // which at 128 registers costs 60 B of spills per lane: without it K2 runs 7 % faster and writes 0.46 GB less
@@ -677,7 +680,9 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
     for (;;) {
         const uint32_t win = s_win;
         if (win >= n_windows) break;
-        const uint32_t wbase = win * EXT_WINDOW;
+        // [r3] K2 walks the pool from its END, k_shade from its beginning: each kernel starts on the windows the other touched last,
+        // i.e. on what the 256 MB memory-side cache still holds of the 3-5 GB the previous launch streamed (PT_K2_REVERSE=0: A/B)
+        const uint32_t wbase = (PT_K2_REVERSE ? n_windows - 1u - win : win) * EXT_WINDOW;
         PT_STAMP(e0);
         // ---- phase A: top level only ---------------------------------------------------------------
         // (PT_K2_PREFETCH: the ray of the NEXT chunk requested before this chunk's traversal starts)
