@@ -1272,12 +1272,14 @@ static_assert(SORT_WINDOW <= 65536, "k_shade: s_perm holds 16-bit slot offsets")
 // same-class slots from an LDS cursor until the window is done — waves execute one material's code
 // instead of serialising through all of them, the expensive classes go first and are spread over all
 // waves of the block (work stealing), and every slot's records are moved whole by its own lane.
-template <bool SORT, int MINW, bool LIGHTS>
-__global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
+// KB: threads per block (256, or [r3] 512 with a 4096-slot window: the sort's barriers and the window's end are paid once per twice
+// as many slots and eight waves level a window's end better than four; one block per CU then).
+template <bool SORT, int MINW, bool LIGHTS, int KB = BLOCK>
+__global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     uint32_t n_done = 0, n_died = 0;   // per thread and launch: far below 2^32 (64-bit counters here were the kernel's only spills)
     const int lane = (int)(threadIdx.x & 63u);
 #ifdef PT_STAMPS
-    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * PROF_COLS; i += BLOCK) (&g_prof[0][0])[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * PROF_COLS; i += KB) (&g_prof[0][0])[i] = 0ull;
     __syncthreads();
 #endif
     uint32_t shard = blockIdx.x % WORK_SHARDS;   // work-counter shard this wave draws from (wave-uniform; moves on when it runs dry)
@@ -1285,22 +1287,24 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
     if (ldu(&cnt->alive) == 0ull) return;   // (see k_extend; a block subtracts its dead slots when it has run out of windows: zero means every window of the pool has been shaded)
     if (!SORT) {
         // n_alloc is a multiple of 256: whole waves run every chunk (wave ballots inside shade_slot)
-        for (uint32_t base = blockIdx.x * BLOCK; base < pool.n_alloc; base += gridDim.x * BLOCK) {
+        for (uint32_t base = blockIdx.x * KB; base < pool.n_alloc; base += gridDim.x * KB) {
             const uint32_t s = base + threadIdx.x;
             const SlotIn in = load_slot_global(pool, s, true);
             shade_slot<LIGHTS>(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, NoPrefetch{});
         }
     } else {
-        __shared__ uint16_t s_perm[SORT_WINDOW];
-        __shared__ uint32_t s_hw[SORT_WINDOW];                  //  8 KB: K2's result words of the window
+        constexpr int WIN = KB * (SORT_WINDOW / BLOCK);         // slots per window: eight per thread
+        static_assert((WIN / KB) * 4 <= 32 && WIN <= 65536 && WIN % 64 == 0, "eight 4-bit keys per thread, 16-bit slot offsets");
+        __shared__ uint16_t s_perm[WIN];
+        __shared__ uint32_t s_hw[WIN];                          //  8 KB: K2's result words of the window
         constexpr uint32_t NCLASS = N_CLASSES, K_DEAD = CLASS_DEAD;   // miss, one per material kind, idle, dead
-        __shared__ uint32_t s_cnt[NCLASS][SORT_WINDOW / 64];   // [class][64-slot group of the window, in slot order]
+        __shared__ uint32_t s_cnt[NCLASS][WIN / 64];   // [class][64-slot group of the window, in slot order]
         __shared__ uint32_t s_hist[NCLASS], s_next;
-        __shared__ uint4 s_stage[BLOCK / 64][STAGE_CHUNKS * 64];   // 24 KB: one staging area per wave (stage_fetch)
-        constexpr int PER = SORT_WINDOW / BLOCK, NGRP = SORT_WINDOW / 64;
+        __shared__ uint4 s_stage[KB / 64][STAGE_CHUNKS * 64];   // 24 KB: one staging area per wave (stage_fetch)
+        constexpr int PER = WIN / KB, NGRP = WIN / 64;
         const int wave = (int)(threadIdx.x >> 6);
         __shared__ uint32_t s_win;
-        const uint32_t n_windows = pool.n_alloc / SORT_WINDOW;
+        const uint32_t n_windows = pool.n_alloc / WIN;
         // The window index of the NEXT round is drawn by thread 0 when its wave has run out of groups and published by the
         // barrier that ends the window anyway: no barrier of its own, and the atomic's round trip (2-3 k cycles the whole
         // block used to sit out at the top of every window) runs while the other waves finish their groups.
@@ -1311,7 +1315,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             const uint32_t win = s_win;
             if (win >= n_windows) break;
             if (threadIdx.x == 0) s_next = 0;      // (every wave is past the previous window's last grab; the first one of this window comes three barriers later)
-            const uint32_t wbase = win * SORT_WINDOW;
+            const uint32_t wbase = win * WIN;
             // classify; STABLE counting sort (slot order is kept inside a class, so the work items a
             // wave dequeues — consecutive pixels of one tile — stay together in a group).
             uint32_t keys = 0;   // 8 x 4-bit class keys: K2 left the class in the top bits of its result word
@@ -1320,8 +1324,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             for (int j = 0; j < PER; ++j) {
                 // the window's result words stay in LDS: the groups take theirs from here instead of gathering 4 bytes per lane
                 // from the pool a second time (a 32-byte sector each)
-                const uint32_t hw = pool.hit_prim[wbase + (uint32_t)j * BLOCK + threadIdx.x];
-                s_hw[(uint32_t)j * BLOCK + threadIdx.x] = hw;
+                const uint32_t hw = pool.hit_prim[wbase + (uint32_t)j * KB + threadIdx.x];
+                s_hw[(uint32_t)j * KB + threadIdx.x] = hw;
                 keys |= (hw >> HIT_CLASS_SHIFT) << (4 * j);
             }
 #pragma unroll
@@ -1339,24 +1343,25 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
                     if ((uint32_t)lane == k) mine = (uint32_t)__popcll(m);
                     todo &= ~m;
                 }
-                if ((uint32_t)lane < NCLASS) s_cnt[lane][j * (BLOCK / 64) + wave] = mine;
+                if ((uint32_t)lane < NCLASS) s_cnt[lane][j * (KB / 64) + wave] = mine;
             }
             __syncthreads();
             // exclusive prefix over the groups in slot order, per class: NGRP = 32 lanes scan one class with five shuffles (the
             // round-1 form — one thread per class walking its 32 counts through LDS, a chain of 32 dependent reads the other
             // 245 threads waited for at the barrier — was a fifth of the sort's time); the block's waves share the classes
-            static_assert(NGRP == 32, "one half-wave per class");
-            for (uint32_t k = (uint32_t)wave * 2u + (uint32_t)(lane >> 5); k < NCLASS; k += (BLOCK / 64) * 2u) {
-                const int g = lane & 31;
+            static_assert(NGRP == 32 || NGRP == 64, "one half-wave or one wave per class");
+            constexpr uint32_t PER_PASS = 64u / (uint32_t)NGRP;          // classes a wave scans at once
+            for (uint32_t k = (uint32_t)wave * PER_PASS + (uint32_t)lane / (uint32_t)NGRP; k < NCLASS; k += (KB / 64) * PER_PASS) {
+                const int g = lane % NGRP;
                 const uint32_t c = s_cnt[k][g];
                 uint32_t incl = c;
 #pragma unroll
-                for (int d = 1; d < 32; d <<= 1) {
-                    const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 32);
+                for (int d = 1; d < NGRP; d <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, d, NGRP);
                     if (g >= d) incl += up;
                 }
                 s_cnt[k][g] = incl - c;
-                if (g == 31) s_hist[k] = incl;
+                if (g == NGRP - 1) s_hist[k] = incl;
             }
             __syncthreads();
             // first position of every class: lane k of each wave sums the histogram below k (eleven LDS reads by eleven lanes)
@@ -1369,11 +1374,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
             for (int j = 0; j < PER; ++j) {
                 const uint32_t key = (keys >> (4 * j)) & 15u;
                 const uint32_t cb = (uint32_t)__shfl((int)my_base, (int)key);
-                const uint32_t pos = cb + s_cnt[key][j * (BLOCK / 64) + wave] + rank[j];
-                s_perm[pos] = (uint16_t)(j * BLOCK + threadIdx.x);
+                const uint32_t pos = cb + s_cnt[key][j * (KB / 64) + wave] + rank[j];
+                s_perm[pos] = (uint16_t)(j * KB + threadIdx.x);
             }
             __syncthreads();
-            const uint32_t n_live = SORT_WINDOW - s_hist[K_DEAD];
+            const uint32_t n_live = (uint32_t)WIN - s_hist[K_DEAD];
             PT_STAMP(w1);
             // groups are taken from the END of the sorted order: the expensive classes (principled, glass) sort
             // last, and starting with them keeps the four waves level when the window runs out (the cheap
@@ -1470,7 +1475,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_shade(SceneD sc, CamD cam, Pool
     if (n_died) atomicSub(&cnt->alive, (unsigned long long)n_died);
 #ifdef PT_STAMPS
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * PROF_COLS; i += BLOCK)
+    for (uint32_t i = threadIdx.x; i < (N_CLASSES + 1) * PROF_COLS; i += KB)
         if ((&g_prof[0][0])[i]) atomicAdd(&cnt->prof[0][0] + i, (&g_prof[0][0])[i]);
 #endif
 }
@@ -1629,19 +1634,24 @@ void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_
     else hipLaunchKernelGGL(pick_extend_batch(sc.tlas_flat, sc.flat_pairs), grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
 }
 typedef void (*shade_fn)(SceneD, CamD, PoolD, CountersD*, uint64_t);
-static shade_fn pick_shade(int variant, bool lights) {   // variant = sort*10 + min waves per SIMD
+static shade_fn pick_shade(int variant, bool lights) {   // variant = sort*10 + min waves per SIMD; 22 = sorted, 512 threads / 4096-slot windows
     switch (variant) {
     case 2: return lights ? k_shade<false, 2, true> : k_shade<false, 2, false>;
     case 3: return lights ? k_shade<false, 3, true> : k_shade<false, 3, false>;
     case 12: return lights ? k_shade<true, 2, true> : k_shade<true, 2, false>;
     case 13: return lights ? k_shade<true, 3, true> : k_shade<true, 3, false>;
+    case 22: return lights ? k_shade<true, 2, true, 512> : k_shade<true, 2, false, 512>;
     default: return lights ? k_shade<false, 2, true> : k_shade<false, 2, false>;
     }
 }
+static int shade_threads(int variant) { return variant == 22 ? 512 : BLOCK; }
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
                   hipStream_t st) {
-    const uint32_t units = variant >= 10 ? (pool.n_alloc / SORT_WINDOW) * BLOCK : pool.n_alloc;   // one block per window / chunk
-    hipLaunchKernelGGL(pick_shade(variant, sc.n_lights != 0u), grid_for(units, max_blocks), dim3(BLOCK), 0, st, sc, cam, pool, cnt, seed);
+    const int kb = shade_threads(variant);
+    uint32_t blocks = variant >= 10 ? pool.n_alloc / (uint32_t)(kb * (SORT_WINDOW / BLOCK)) : (pool.n_alloc + (uint32_t)kb - 1u) / (uint32_t)kb;   // one block per window / chunk
+    if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(pick_shade(variant, sc.n_lights != 0u), dim3(blocks), dim3((uint32_t)kb), 0, st, sc, cam, pool, cnt, seed);
 }
 void launch_resolve(const PoolD& pool, double* accum, int max_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, grid_for(pool.n_pixels, max_blocks), dim3(BLOCK), 0, st, pool, accum);
@@ -1666,7 +1676,7 @@ void launch_math_probe(int which, const double* in, uint32_t n, double* out, hip
 int kernel_occupancy_blocks(int which, int variant, bool lights) {
     int nb = 0;
     const void* f = which == 0 ? (variant <= -100 ? (const void*)pick_extend2(-variant) : (const void*)pick_extend_batch(variant <= -2, variant == -3)) : (const void*)pick_shade(variant, lights);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, which == 1 ? shade_threads(variant) : BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
