@@ -19,5 +19,6 @@ void launch_math_probe(int which, const double* in, uint32_t n, double* out, hip
 // K2 variant code (`code` of launch_extend / `variant` of kernel_occupancy_blocks): -1 = batch kernel (-2 asks
 // kernel_occupancy_blocks for its flat-top-level instantiation), -(stack*10 + blocks) = two-phase kernel
 // k_extend2<stack, blocks> for stack in {16, 20, 24}.
+void set_wide_window_min(uint32_t n);   // k_shade variant 42: windows per launched block from which the 8192-slot window is used
 int kernel_occupancy_blocks(int which, int variant, bool lights = false);   // lights: k_shade's instantiation for scenes with a lights list   // 0 = extend, 1 = shade; resident blocks per CU
 }  // namespace pt

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(CamD cam, PoolD pool, uint64_t s
     }
 }
 
+template <int STRIDE = BLOCK>
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best);
 
 // ---- the FLAT top level (SceneD::tlas_flat: at most TLAS_FLAT_MAX world entries), walked by a whole wave ---------------------
@@ -623,11 +624,15 @@ __shared__ unsigned long long g_prof[N_CLASSES + 1][PROF_COLS];
 #endif                               // which at 128 registers costs 60 B of spills per lane: without it K2 runs 7 % faster and writes 0.46 GB less
 
 constexpr int EXT_WINDOW = 2048;   // slots per block window
-constexpr uint32_t REFILL_MIN = 16;   // idle lanes that trigger a refill of the wave in phase B
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 16
+#endif
+constexpr uint32_t REFILL_MIN = PT_REFILL_MIN;   // idle lanes that trigger a refill of the wave in phase B
 constexpr int EXT_CAND = 768;      // candidate list of a window (LDS); a fuller window walks the rest in phase A
 static_assert(EXT_WINDOW % BLOCK == 0 && EXT_WINDOW <= 65536, "k_extend2: s_cand_sl holds 16-bit slot offsets inside the window");
 static_assert(EXT_WINDOW == SORT_WINDOW_SLOTS, "the pool is allocated in whole windows of this size (pt_render.cpp rounds n_alloc to 2048)");
 
+template <int STRIDE>   // STRIDE: threads per block = distance of a lane's consecutive stack entries in LDS
 PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double t_min, float t_min_f, uint32_t* stk, int cap, Closest& best) {
     const RayD r = ray_to_local_chain(sc, e.inst, wray);
     const RayF f = make_rayf(r.o, r.d, e.extent);
@@ -641,9 +646,9 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
         while ((cur & REF_TYPE_MASK) == REF_NODE) {
             uint32_t c0, c1;
             const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
-            if (n == 2 && sp < cap) stk[(sp++) * BLOCK] = c1;
+            if (n == 2 && sp < cap) stk[(sp++) * STRIDE] = c1;
             if (n > 0) cur = c0;
-            else if (sp > 0) cur = stk[(--sp) * BLOCK];
+            else if (sp > 0) cur = stk[(--sp) * STRIDE];
             else cur = REF_EMPTY;
         }
         if ((cur & REF_TYPE_MASK) != REF_TRIS) break;             // REF_EMPTY: nothing left
@@ -651,24 +656,26 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
         test_leaf(sc, first, count, r, t_min, e.first_prim, best);
         t_max_f = t_max_f32(best.t);
         if (sp == 0) break;
-        cur = stk[(--sp) * BLOCK];
+        cur = stk[(--sp) * STRIDE];
     }
 }
 
-template <int EXT_STACK, int MINB>
-__global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
-    __shared__ uint32_t stack[EXT_STACK * BLOCK];
-    __shared__ uint32_t s_best_id[EXT_WINDOW];                     //  8 KB  closest primitive of every slot of the window
-    __shared__ double s_cand_t[EXT_CAND];                          //  6 KB  candidates (rays that entered mesh boxes): phase-A best t,
-    __shared__ uint32_t s_cand_items[EXT_CAND];                    //  3 KB  recorded mesh entries, 8 bit each, 0xFF = none,
-    __shared__ uint16_t s_cand_sl[EXT_CAND];                       //        slot inside the window
+// KB: threads per block (256; [r3] other sizes for A/B — the window and the candidate list scale with it; MINB = waves per SIMD, which is what hipcc's launch bound means)
+template <int EXT_STACK, int MINB, int KB = BLOCK>
+__global__ __launch_bounds__(KB, MINB) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
+    constexpr int WIN = EXT_WINDOW / BLOCK * KB, CAND = EXT_CAND / BLOCK * KB;
+    __shared__ uint32_t stack[EXT_STACK * KB];
+    __shared__ uint32_t s_best_id[WIN];                            //  8 KB  closest primitive of every slot of the window
+    __shared__ double s_cand_t[CAND];                              //  6 KB  candidates (rays that entered mesh boxes): phase-A best t,
+    __shared__ uint32_t s_cand_items[CAND];                        //  3 KB  recorded mesh entries, 8 bit each, 0xFF = none,
+    __shared__ uint16_t s_cand_sl[CAND];                           //        slot inside the window
     __shared__ uint32_t s_nrays, s_next, s_win;
     uint32_t* stk = &stack[threadIdx.x];
     const int lane = (int)(threadIdx.x & 63u);
     const double t_min = 1e-3;                                     // camera.rs:171,179
     const float t_min_f = __double2float_rd(t_min);
     unsigned long long nseg = 0;
-    const uint32_t n_windows = pool.n_alloc / EXT_WINDOW;
+    const uint32_t n_windows = pool.n_alloc / WIN;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
     if (ldu(&cnt->alive) == 0ull) return;   // (see k_extend)
 #ifdef PT_STAMPS
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         if (win >= n_windows) break;
         // [r3] K2 walks the pool from its END, k_shade from its beginning: each kernel starts on the windows the other touched last,
         // i.e. on what the 256 MB memory-side cache still holds of the 3-5 GB the previous launch streamed (PT_K2_REVERSE=0: A/B)
-        const uint32_t wbase = (PT_K2_REVERSE ? n_windows - 1u - win : win) * EXT_WINDOW;
+        const uint32_t wbase = (PT_K2_REVERSE ? n_windows - 1u - win : win) * WIN;
         PT_STAMP(e0);
         // ---- phase A: top level only ---------------------------------------------------------------
         // (PT_K2_PREFETCH: the ray of the NEXT chunk requested before this chunk's traversal starts)
@@ -691,15 +698,15 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         RayD r_next{};
         if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + threadIdx.x);
 #endif
-        for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) {
-            const uint32_t sl = (uint32_t)j * BLOCK + threadIdx.x;
+        for (int j = 0; j < WIN / KB; ++j) {
+            const uint32_t sl = (uint32_t)j * KB + threadIdx.x;
 #if PT_K2_PREFETCH
             const uint32_t state = state_next;
             const bool alive = state < SLOT_IDLE;
             const RayD r = r_next;
-            if (j + 1 < EXT_WINDOW / BLOCK) {
-                state_next = pool.bounce[wbase + sl + BLOCK];
-                if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + sl + BLOCK);
+            if (j + 1 < WIN / KB) {
+                state_next = pool.bounce[wbase + sl + KB];
+                if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + sl + KB);
             }
 #else
             const uint32_t state = pool.bounce[wbase + sl];
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                         items = (items & ~(0xFFu << (8u * n_my))) | (ei << (8u * n_my));   // defer to phase B
                         ++n_my;
                     } else {
-                        blas_pass(sc, r, e, t_min, t_min_f, stk + (size_t)sp * BLOCK, EXT_STACK - sp, best);   // a fifth mesh / a wide index: walk it now
+                        blas_pass<KB>(sc, r, e, t_min, t_min_f, stk + (size_t)sp * KB, EXT_STACK - sp, best);   // a fifth mesh / a wide index: walk it now
                         t_max_f = t_max_f32(best.t);
                     }
                 } else {
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                     if ((cur & REF_TYPE_MASK) == REF_NODE) {
                         uint32_t c0, c1;
                         const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
-                        if (n == 2 && sp < EXT_STACK) stk[(sp++) * BLOCK] = c1;
+                        if (n == 2 && sp < EXT_STACK) stk[(sp++) * KB] = c1;
                         if (n > 0) {
                             cur = c0;
                             continue;
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                         visit_entry(std::false_type{}, ei, sc.entries[ei], sp);
                     }
                     if (sp == 0) break;
-                    cur = stk[(--sp) * BLOCK];
+                    cur = stk[(--sp) * KB];
                 }
             }
             // append the rays that recorded meshes to the window's candidate list (one LDS atomic per wave, slot
@@ -771,12 +778,12 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 base = (uint32_t)__shfl((int)base, leader);
                 if (n_my > 0) {
                     const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < (uint32_t)EXT_CAND) {
+                    if (pos < (uint32_t)CAND) {
                         s_cand_t[pos] = best.t;
                         s_cand_items[pos] = items;
                         s_cand_sl[pos] = (uint16_t)sl;
                     } else {
-                        for (uint32_t k = 0; k < n_my; ++k) blas_pass(sc, r, sc.entries[(items >> (8u * k)) & 0xFFu], t_min, t_min_f, stk, EXT_STACK, best);
+                        for (uint32_t k = 0; k < n_my; ++k) blas_pass<KB>(sc, r, sc.entries[(items >> (8u * k)) & 0xFFu], t_min, t_min_f, stk, EXT_STACK, best);
                     }
                 }
             }
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         __syncthreads();
         PT_STAMP(e2);
         // ---- phase B: mesh traversals, 64 rays per pull ------------------------------------------------
-        const uint32_t n_rays = s_nrays < (uint32_t)EXT_CAND ? s_nrays : (uint32_t)EXT_CAND;
+        const uint32_t n_rays = s_nrays < (uint32_t)CAND ? s_nrays : (uint32_t)CAND;
         {
             // Lanes are refilled: a lane whose ray is done does not wait for the longest ray of a fixed group of 64 —
             // when at least REFILL_MIN lanes of the wave are idle they draw the next candidates from the list (one
@@ -838,9 +845,9 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                 while (busy && (cur & REF_TYPE_MASK) == REF_NODE) {
                     uint32_t c0, c1;
                     const int n = visit_node(&sc.nodes[cur], f, t_min_f, t_max_f, c0, c1);
-                    if (n == 2 && sp < EXT_STACK) stk[(sp++) * BLOCK] = c1;
+                    if (n == 2 && sp < EXT_STACK) stk[(sp++) * KB] = c1;
                     if (n > 0) cur = c0;
-                    else if (sp > 0) cur = stk[(--sp) * BLOCK];
+                    else if (sp > 0) cur = stk[(--sp) * KB];
                     else cur = REF_EMPTY;
                 }
                 if (busy) {
@@ -848,7 +855,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
                         const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 7u) + 1u;
                         test_leaf(sc, first, count, r, t_min, first_prim, best);
                         t_max_f = t_max_f32(best.t);
-                        cur = sp > 0 ? stk[(--sp) * BLOCK] : REF_EMPTY;
+                        cur = sp > 0 ? stk[(--sp) * KB] : REF_EMPTY;
                     }
                     if (cur == REF_EMPTY) {                         // this mesh is done: the ray's next mesh, or the ray is done
                         ++item_k;
@@ -874,11 +881,11 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_extend2(SceneD sc, PoolD pool, 
         }
 #endif
         {   // the window's result: one coalesced 4-byte store per slot; the eight PrimRef gathers (material class) go out together
-            uint32_t word[EXT_WINDOW / BLOCK];
+            uint32_t word[WIN / KB];
 #pragma unroll
-            for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) word[j] = hit_word(sc, s_best_id[(uint32_t)j * BLOCK + threadIdx.x]);
+            for (int j = 0; j < WIN / KB; ++j) word[j] = hit_word(sc, s_best_id[(uint32_t)j * KB + threadIdx.x]);
 #pragma unroll
-            for (int j = 0; j < EXT_WINDOW / BLOCK; ++j) stnt(&pool.hit_prim[wbase + (uint32_t)j * BLOCK + threadIdx.x], word[j]);
+            for (int j = 0; j < WIN / KB; ++j) stnt(&pool.hit_prim[wbase + (uint32_t)j * KB + threadIdx.x], word[j]);
         }
         if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_extend, 1ull); s_nrays = 0; s_next = 0; }   // all of this window's uses are behind the barrier above
         __syncthreads();   // LDS lists are reused by the next window
@@ -1274,7 +1281,7 @@ static_assert(SORT_WINDOW <= 65536, "k_shade: s_perm holds 16-bit slot offsets")
 // waves of the block (work stealing), and every slot's records are moved whole by its own lane.
 // KB: threads per block (256, or [r3] 512 with a 4096-slot window: the sort's barriers and the window's end are paid once per twice
 // as many slots and eight waves level a window's end better than four; one block per CU then).
-template <bool SORT, int MINW, bool LIGHTS, int KB = BLOCK>
+template <bool SORT, int MINW, bool LIGHTS, int KB = BLOCK, int PER = SORT_WINDOW / BLOCK>
 __global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc, CamD cam, PoolD pool, CountersD* cnt, uint64_t seed) {
     uint32_t n_done = 0, n_died = 0;   // per thread and launch: far below 2^32 (64-bit counters here were the kernel's only spills)
     const int lane = (int)(threadIdx.x & 63u);
@@ -1293,15 +1300,15 @@ __global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc,
             shade_slot<LIGHTS>(sc, cam, pool, cnt, seed, s, lane, in, shard, n_done, n_died, NoPrefetch{});
         }
     } else {
-        constexpr int WIN = KB * (SORT_WINDOW / BLOCK);         // slots per window: eight per thread
-        static_assert((WIN / KB) * 4 <= 32 && WIN <= 65536 && WIN % 64 == 0, "eight 4-bit keys per thread, 16-bit slot offsets");
+        constexpr int WIN = KB * PER;                           // slots per window: eight (or sixteen) per thread
+        static_assert(PER * 4 <= 64 && WIN <= 65536 && WIN % 64 == 0, "sixteen 4-bit keys per thread at most, 16-bit slot offsets");
         __shared__ uint16_t s_perm[WIN];
         __shared__ uint32_t s_hw[WIN];                          //  8 KB: K2's result words of the window
         constexpr uint32_t NCLASS = N_CLASSES, K_DEAD = CLASS_DEAD;   // miss, one per material kind, idle, dead
         __shared__ uint32_t s_cnt[NCLASS][WIN / 64];   // [class][64-slot group of the window, in slot order]
         __shared__ uint32_t s_hist[NCLASS], s_next;
         __shared__ uint4 s_stage[KB / 64][STAGE_CHUNKS * 64];   // 24 KB: one staging area per wave (stage_fetch)
-        constexpr int PER = WIN / KB, NGRP = WIN / 64;
+        constexpr int NGRP = WIN / 64;
         const int wave = (int)(threadIdx.x >> 6);
         __shared__ uint32_t s_win;
         const uint32_t n_windows = pool.n_alloc / WIN;
@@ -1318,7 +1325,7 @@ __global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc,
             const uint32_t wbase = win * WIN;
             // classify; STABLE counting sort (slot order is kept inside a class, so the work items a
             // wave dequeues — consecutive pixels of one tile — stay together in a group).
-            uint32_t keys = 0;   // 8 x 4-bit class keys: K2 left the class in the top bits of its result word
+            typename std::conditional<(PER > 8), uint64_t, uint32_t>::type keys = 0;   // PER x 4-bit class keys: K2 left the class in the top bits of its result word
             uint32_t rank[PER];
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -1326,11 +1333,11 @@ __global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc,
                 // from the pool a second time (a 32-byte sector each)
                 const uint32_t hw = pool.hit_prim[wbase + (uint32_t)j * KB + threadIdx.x];
                 s_hw[(uint32_t)j * KB + threadIdx.x] = hw;
-                keys |= (hw >> HIT_CLASS_SHIFT) << (4 * j);
+                keys |= (decltype(keys))(hw >> HIT_CLASS_SHIFT) << (4 * j);
             }
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
-                const uint32_t key = (keys >> (4 * j)) & 15u;
+                const uint32_t key = (uint32_t)(keys >> (4 * j)) & 15u;
                 rank[j] = 0;
                 // only the classes present among the wave's 64 slots cost a ballot (typically two to four); lane k keeps class k's
                 // count and stores it — one LDS store per wave and chunk ([r3]; lane 0 used to zero eleven words and write the rest)
@@ -1349,7 +1356,8 @@ __global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc,
             // exclusive prefix over the groups in slot order, per class: NGRP = 32 lanes scan one class with five shuffles (the
             // round-1 form — one thread per class walking its 32 counts through LDS, a chain of 32 dependent reads the other
             // 245 threads waited for at the barrier — was a fifth of the sort's time); the block's waves share the classes
-            static_assert(NGRP == 32 || NGRP == 64, "one half-wave or one wave per class");
+            static_assert(NGRP == 32 || NGRP == 64 || NGRP == 128, "one half-wave or one wave per class (two counts per lane for 128)");
+            if constexpr (NGRP <= 64) {
             constexpr uint32_t PER_PASS = 64u / (uint32_t)NGRP;          // classes a wave scans at once
             for (uint32_t k = (uint32_t)wave * PER_PASS + (uint32_t)lane / (uint32_t)NGRP; k < NCLASS; k += (KB / 64) * PER_PASS) {
                 const int g = lane % NGRP;
@@ -1363,6 +1371,20 @@ __global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc,
                 s_cnt[k][g] = incl - c;
                 if (g == NGRP - 1) s_hist[k] = incl;
             }
+            } else {
+            for (uint32_t k = (uint32_t)wave; k < NCLASS; k += KB / 64) {
+                const uint32_t c0 = s_cnt[k][2 * lane], c1 = s_cnt[k][2 * lane + 1];
+                uint32_t incl = c0 + c1;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+                    if (lane >= d) incl += up;
+                }
+                s_cnt[k][2 * lane] = incl - c0 - c1;
+                s_cnt[k][2 * lane + 1] = incl - c1;
+                if (lane == 63) s_hist[k] = incl;
+            }
+            }
             __syncthreads();
             // first position of every class: lane k of each wave sums the histogram below k (eleven LDS reads by eleven lanes)
             // and the slots fetch theirs by a lane shuffle ([r3]; every thread used to build the table and select from it with
@@ -1372,7 +1394,7 @@ __global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc,
                 for (uint32_t k = 0; k < (uint32_t)lane; ++k) my_base += s_hist[k];
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
-                const uint32_t key = (keys >> (4 * j)) & 15u;
+                const uint32_t key = (uint32_t)(keys >> (4 * j)) & 15u;
                 const uint32_t cb = (uint32_t)__shfl((int)my_base, (int)key);
                 const uint32_t pos = cb + s_cnt[key][j * (KB / 64) + wave] + rank[j];
                 s_perm[pos] = (uint16_t)(j * KB + threadIdx.x);
@@ -1622,15 +1644,25 @@ static extend2_fn pick_extend2(int code) {   // code = stack entries * 10 + min 
     case 204: return k_extend2<20, 4>;
     case 283: return k_extend2<28, 3>;   // deep trees (the GPU builder's LBVHs of million-triangle meshes): 47.5 / 51.5 KB of LDS per block,
     case 323: return k_extend2<32, 3>;   // still three blocks per CU (160 KB)
+    case 1164: return k_extend2<16, 4, 64>;    // [r3] block-size A/B (PT_EXT2): one wave per block and 512-slot windows ...
+    case 2164: return k_extend2<16, 4, 128>;
+    case 8164: return k_extend2<16, 4, 512>;   // ... to eight waves and 4096-slot windows
     default: return k_extend2<24, 3>;   // 24 stack entries: 43.5 KB of LDS per block, three blocks per CU
     }
 }
+static int extend2_threads(int code) { return code >= 1000 ? (code / 1000) * 64 : BLOCK; }
 typedef void (*extend_fn)(SceneD, PoolD, CountersD*);
 static extend_fn pick_extend_batch(uint32_t flat, uint32_t pairs) {
     return !flat ? k_extend<false, false> : pairs ? k_extend<true, true> : k_extend<true, false>;
 }
 void launch_extend(const SceneD& sc, const PoolD& pool, CountersD* cnt, int max_blocks, int code, hipStream_t st) {   // code: pt_render.cpp extend_code
-    if (code <= -100) hipLaunchKernelGGL(pick_extend2(-code), grid_for((pool.n_alloc / EXT_WINDOW) * BLOCK, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
+    if (code <= -100) {
+        const int kb = extend2_threads(-code);
+        uint32_t blocks = pool.n_alloc / (uint32_t)(EXT_WINDOW / BLOCK * kb);   // one per window at most
+        if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
+        if (blocks == 0) blocks = 1;
+        hipLaunchKernelGGL(pick_extend2(-code), dim3(blocks), dim3((uint32_t)kb), 0, st, sc, pool, cnt);
+    }
     else hipLaunchKernelGGL(pick_extend_batch(sc.tlas_flat, sc.flat_pairs), grid_for(pool.n_alloc, max_blocks), dim3(BLOCK), 0, st, sc, pool, cnt);
 }
 typedef void (*shade_fn)(SceneD, CamD, PoolD, CountersD*, uint64_t);
@@ -1641,14 +1673,21 @@ static shade_fn pick_shade(int variant, bool lights) {   // variant = sort*10 + 
     case 12: return lights ? k_shade<true, 2, true> : k_shade<true, 2, false>;
     case 13: return lights ? k_shade<true, 3, true> : k_shade<true, 3, false>;
     case 22: return lights ? k_shade<true, 2, true, 512> : k_shade<true, 2, false, 512>;
+    case 32: case 42: return lights ? k_shade<true, 2, true, 512, 16> : k_shade<true, 2, false, 512, 16>;
     default: return lights ? k_shade<false, 2, true> : k_shade<false, 2, false>;
     }
 }
-static int shade_threads(int variant) { return variant == 22 ? 512 : BLOCK; }
+static int shade_threads(int variant) { return variant == 22 || variant == 32 || variant == 42 ? 512 : BLOCK; }
+static uint32_t wide_window_min = 16;
+void set_wide_window_min(uint32_t n) { wide_window_min = n ? n : 1u; }
+static int shade_window(int variant) { return variant == 32 ? 8192 : variant == 22 ? 4096 : SORT_WINDOW; }
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
                   hipStream_t st) {
+    // 42: 8192-slot windows while the pool holds at least PT_WIDE_WINDOW_MIN of them per block launched, 4096-slot windows below
+    // (a thinner pool — smaller frames, one rank's share, the frame's end after compaction — levels its end better with more, smaller windows)
+    if (variant == 42) variant = pool.n_alloc / 8192u >= (uint32_t)max_blocks * wide_window_min ? 32 : 22;
     const int kb = shade_threads(variant);
-    uint32_t blocks = variant >= 10 ? pool.n_alloc / (uint32_t)(kb * (SORT_WINDOW / BLOCK)) : (pool.n_alloc + (uint32_t)kb - 1u) / (uint32_t)kb;   // one block per window / chunk
+    uint32_t blocks = variant >= 10 ? pool.n_alloc / (uint32_t)shade_window(variant) : (pool.n_alloc + (uint32_t)kb - 1u) / (uint32_t)kb;   // one block per window / chunk
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(pick_shade(variant, sc.n_lights != 0u), dim3(blocks), dim3((uint32_t)kb), 0, st, sc, cam, pool, cnt, seed);
@@ -1676,7 +1715,7 @@ void launch_math_probe(int which, const double* in, uint32_t n, double* out, hip
 int kernel_occupancy_blocks(int which, int variant, bool lights) {
     int nb = 0;
     const void* f = which == 0 ? (variant <= -100 ? (const void*)pick_extend2(-variant) : (const void*)pick_extend_batch(variant <= -2, variant == -3)) : (const void*)pick_shade(variant, lights);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, which == 1 ? shade_threads(variant) : BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, which == 1 ? shade_threads(variant) : variant <= -100 ? extend2_threads(-variant) : BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 

@@ -240,7 +240,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     if (n_slots64 > 0x7FFFFFC0ull) return set_error("pt_render: image too large for the path pool");
     const uint32_t n_slots = (uint32_t)n_slots64;
     // one allocation: the two record arrays (RayRec, PathRec), the static mode's f64 arrays, the two u32 state arrays
-    const size_t n_al = ((size_t)n_slots + 4095) & ~(size_t)4095;   // whole windows: 2048 slots (k_extend2, k_shade) / 4096 (k_shade with 512 threads)
+    const size_t n_al = ((size_t)n_slots + 8191) & ~(size_t)8191;   // whole windows: 2048 slots (k_extend2, k_shade) / 4096 (k_shade with 512 threads)
     const size_t bytes = n_al * (sizeof(RayRec) + sizeof(PathRec) + 6 * sizeof(double) + 2 * sizeof(uint32_t));
     if (bytes > s->pool_bytes) {
         if (s->pool_mem) (void)hipFree(s->pool_mem);
@@ -299,9 +299,12 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     // persistent grids: resident blocks per CU x CUs
     int mult = 1;
     if (const char* e = exp_env("PT_GRID_MULT")) mult = std::max(1, atoi(e));
-    int shade_variant = 22;   // k_shade<sort, min waves/SIMD>: sort*10 + waves (12 = windowed material sort with 256 threads / 2048-slot windows, 2 = plain;
-                              // [r3] 22 = the same with 512 threads / 4096-slot windows: K3 -2 % on scenes 6, 3 and 5)
+    int shade_variant = 42;   // k_shade<sort, min waves/SIMD>: sort*10 + waves (12 = windowed material sort with 256 threads / 2048-slot windows, 2 = plain;
+                              // [r3] 22 = the same with 512 threads / 4096-slot windows: K3 -2 % on scenes 6, 3 and 5; 32 = 8192-slot windows: another
+                              // -1.6 % on scene 6's 33.6 M-slot pool, +2.5 % on scene 5's 16.8 M; 42 = per launch, 32 while the pool holds >= 16 such
+                              // windows per block launched, else 22)
     if (const char* e = exp_env("PT_SHADE_VARIANT")) shade_variant = atoi(e);
+    if (const char* e = exp_env("PT_WIDE_WINDOW_MIN")) set_wide_window_min((uint32_t)std::max(1, atoi(e)));
     // K2 variant: two-phase kernel when there are meshes to defer and its LDS stack covers the scene's BVHs, else the
     // batch kernel. Experiment switches: PT_K2=batch forces the batch kernel; PT_EXT2 = stack*10 + blocks per CU picks
     // the instantiation. extend_code: -1 = batch, -(stack*10 + blocks) = two-phase.
@@ -315,6 +318,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (const char* e = exp_env("PT_EXT2")) {
             const int c = atoi(e);
             if (c / 10 >= need && (c == 163 || c == 164 || c == 204 || c == 243 || c == 283 || c == 323)) code = c;
+            if ((c == 1164 || c == 2164 || c == 8164) && need <= 16) code = c;
         }
         return code;
     };
@@ -396,8 +400,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         if (poll_every < poll_cap) poll_every *= 2;     // (a poll is a pipeline drain of some tens of microseconds: every 8 iterations costs <= 0.5 %)
         // the frame's end: once half of the slots still covered are dead the survivors move to the front and the launches shrink with them
         // (k_compact_scan / k_compact_move). The count is the last poll's — stale only towards MORE live slots, which errs on the safe side.
-        if (compact_ok && alive && n_alive * compact_den <= (uint64_t)pool.n_alloc * compact_num && pool.n_alloc > 4 * 4096u) {
-            const uint32_t new_end = (uint32_t)((n_alive + 4095) & ~(uint64_t)4095);
+        if (compact_ok && alive && n_alive * compact_den <= (uint64_t)pool.n_alloc * compact_num && pool.n_alloc > 4 * 8192u) {
+            const uint32_t new_end = (uint32_t)((n_alive + 8191) & ~(uint64_t)8191);
             const uint32_t cap = new_end;                                  // holes and movers are both at most the live count
             const size_t words = 2 * (size_t)cap + 2;
             if (words > s->compact_scratch_words) {
