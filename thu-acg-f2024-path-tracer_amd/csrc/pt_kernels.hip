@@ -1678,14 +1678,12 @@ static shade_fn pick_shade(int variant, bool lights) {   // variant = sort*10 + 
     }
 }
 static int shade_threads(int variant) { return variant == 22 || variant == 32 || variant == 42 ? 512 : BLOCK; }
-static uint32_t wide_window_min = 16;
-void set_wide_window_min(uint32_t n) { wide_window_min = n ? n : 1u; }
 static int shade_window(int variant) { return variant == 32 ? 8192 : variant == 22 ? 4096 : SORT_WINDOW; }
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
-                  hipStream_t st) {
+                  hipStream_t st, uint32_t wide_window_min) {
     // 42: 8192-slot windows while the pool holds at least PT_WIDE_WINDOW_MIN of them per block launched, 4096-slot windows below
     // (a thinner pool — smaller frames, one rank's share, the frame's end after compaction — levels its end better with more, smaller windows)
-    if (variant == 42) variant = pool.n_alloc / 8192u >= (uint32_t)max_blocks * wide_window_min ? 32 : 22;
+    if (variant == 42) variant = pool.n_alloc / 8192u >= (uint32_t)max_blocks * (wide_window_min ? wide_window_min : 1u) ? 32 : 22;
     const int kb = shade_threads(variant);
     uint32_t blocks = variant >= 10 ? pool.n_alloc / (uint32_t)shade_window(variant) : (pool.n_alloc + (uint32_t)kb - 1u) / (uint32_t)kb;   // one block per window / chunk
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;

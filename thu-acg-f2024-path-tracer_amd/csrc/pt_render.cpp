@@ -304,7 +304,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
                               // -1.6 % on scene 6's 33.6 M-slot pool, +2.5 % on scene 5's 16.8 M; 42 = per launch, 32 while the pool holds >= 16 such
                               // windows per block launched, else 22)
     if (const char* e = exp_env("PT_SHADE_VARIANT")) shade_variant = atoi(e);
-    if (const char* e = exp_env("PT_WIDE_WINDOW_MIN")) set_wide_window_min((uint32_t)std::max(1, atoi(e)));
+    uint32_t wide_window_min = 16;
+    if (const char* e = exp_env("PT_WIDE_WINDOW_MIN")) wide_window_min = (uint32_t)std::max(1, atoi(e));
     // K2 variant: two-phase kernel when there are meshes to defer and its LDS stack covers the scene's BVHs, else the
     // batch kernel. Experiment switches: PT_K2=batch forces the batch kernel; PT_EXT2 = stack*10 + blocks per CU picks
     // the instantiation. extend_code: -1 = batch, -(stack*10 + blocks) = two-phase.
@@ -387,7 +388,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
             launch_extend(s->dev.view, pool, s->d_counters, grid_extend, extend_code, st);
             timer.end(st);
             timer.begin(1, st);
-            launch_shade(s->dev.view, dc, pool, s->d_counters, seed, grid_shade, shade_variant, st);
+            launch_shade(s->dev.view, dc, pool, s->d_counters, seed, grid_shade, shade_variant, st, wide_window_min);
             timer.end(st);
             ++iterations;
         }
