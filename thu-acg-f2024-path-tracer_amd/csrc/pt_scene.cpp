@@ -351,6 +351,9 @@ struct Builder {
     std::vector<uint32_t>* order;          // BLAS: output permutation (leaf order)
     uint32_t leaf_base = 0;                // BLAS: index of this mesh's first triangle in the global array
     int depth_reached = 0;
+    int n_bins = 16;                       // SAH bins per axis (<= MAX_BINS)
+    size_t sweep_below = 0;                // ranges of at most this many items are split by the exact SAH sweep (every split position of every axis)
+    static constexpr int MAX_BINS = 64;
 
     static float down(double v) {
         float f = (float)v;
@@ -397,15 +400,40 @@ struct Builder {
         int axis = ext.x >= ext.y && ext.x >= ext.z ? 0 : (ext.y >= ext.z ? 1 : 2);
         size_t mid = begin + n / 2;
         bool done = false;
-        if (!force_median) {
-            const int NB = 16;
+        if (!force_median && n <= sweep_below) {
+            // exact sweep: the items sorted along each axis, every position between two neighbours a candidate
+            double best_cost = INFINITY;
+            int best_axis = -1;
+            size_t best_pos = 0;
+            std::vector<BuildItem> tmp(items.begin() + begin, items.begin() + end);
+            std::vector<double> right_area(n);
+            for (int a = 0; a < 3; ++a) {
+                std::stable_sort(tmp.begin(), tmp.end(), [&](const BuildItem& x, const BuildItem& y) { return axis_of(x.c, a) < axis_of(y.c, a); });
+                Box acc;
+                for (size_t i = n; i-- > 1;) { acc.grow(tmp[i].box); right_area[i] = acc.half_area(); }
+                acc = Box();
+                for (size_t i = 0; i + 1 < n; ++i) {
+                    acc.grow(tmp[i].box);
+                    const double cost = acc.half_area() * (double)(i + 1) + right_area[i + 1] * (double)(n - i - 1);
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_pos = i + 1; }
+                }
+            }
+            if (best_axis >= 0) {
+                std::stable_sort(items.begin() + begin, items.begin() + end,
+                                 [&](const BuildItem& x, const BuildItem& y) { return axis_of(x.c, best_axis) < axis_of(y.c, best_axis); });
+                mid = begin + best_pos;
+                done = true;
+            }
+        }
+        if (!force_median && !done) {
+            const int NB = n_bins;
             double best_cost = INFINITY;
             int best_axis = -1, best_bin = -1;
             for (int a = 0; a < 3; ++a) {
                 double lo = axis_of(cbox.lo, a), hi = axis_of(cbox.hi, a);
                 if (!(hi > lo)) continue;
-                Box bb[NB];
-                size_t bc[NB] = {0};
+                Box bb[MAX_BINS];
+                size_t bc[MAX_BINS] = {0};
                 double k = (double)NB / (hi - lo);
                 for (size_t i = begin; i < end; ++i) {
                     int b = (int)((axis_of(items[i].c, a) - lo) * k);
@@ -413,8 +441,8 @@ struct Builder {
                     bb[b].grow(items[i].box);
                     ++bc[b];
                 }
-                Box right_acc[NB];
-                size_t right_cnt[NB];
+                Box right_acc[MAX_BINS];
+                size_t right_cnt[MAX_BINS];
                 Box acc;
                 size_t cnt = 0;
                 for (int b = NB - 1; b > 0; --b) {
@@ -435,10 +463,10 @@ struct Builder {
             }
             if (best_axis >= 0) {
                 double lo = axis_of(cbox.lo, best_axis), hi = axis_of(cbox.hi, best_axis);
-                double k = 16.0 / (hi - lo);
+                double k = (double)NB / (hi - lo);
                 auto it = std::stable_partition(items.begin() + begin, items.begin() + end, [&](const BuildItem& it_) {
                     int b = (int)((axis_of(it_.c, best_axis) - lo) * k);
-                    b = std::min(std::max(b, 0), 15);
+                    b = std::min(std::max(b, 0), NB - 1);
                     return b <= best_bin;
                 });
                 mid = (size_t)(it - items.begin());
@@ -643,6 +671,8 @@ int pt::scene_build(pt_scene* s) {
                 }
                 if (!on_device) {
                     Builder bl{nodes, items, leaf_max, MAX_BLAS_DEPTH, true, &perm, sb.tri_base};
+                    if (const char* ev = exp_env("PT_SAH_BINS")) bl.n_bins = std::min((int)Builder::MAX_BINS, std::max(2, atoi(ev)));
+                    if (const char* ev = exp_env("PT_SAH_SWEEP")) bl.sweep_below = (size_t)std::max(0, atoi(ev));
                     sb.root = bl.build(0, items.size(), 0, bb);
                     max_blas_depth = std::max(max_blas_depth, bl.depth_reached);
                 }
