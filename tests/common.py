@@ -314,3 +314,26 @@ def free_placement_scene():
     spec.add("world_build")
     spec.camera = default_camera(width=64, look_from=(0.0, 2.2, -6.0), look_at=(0.0, 0.8, 0.0), vfov=48.0, env_color=(0.06, 0.07, 0.1))
     return spec
+
+
+def white_furnace_scene(width=256, aspect=1.0):
+    """A closed-form property of the whole pipeline (no oracle needed, any image size): white Lambertian objects — a floor, a sphere,
+    a cuboid and a mesh — under a CONSTANT environment and no lights list. A cosine-sampled diffuse bounce has eval / pdf = albedo = 1
+    (diffuse.rs:53-63 over camera.rs:207-213), Russian roulette keeps a path of luminance 1 with probability 1 (camera.rs:190-196),
+    so every sample carries exactly the environment's colour out of the scene, whatever it bounced off. No Instance on purpose: under
+    a rotation the reference keeps the shading normal in object space (instance.rs:49-53), samples some directions INTO
+    the surface and loses those paths inside the closed object — 1.6 % of the samples of this scene when the cuboid and the mesh are
+    instanced (measured on the oracle); that is the reference's behaviour, reproduced, and not what this test is about."""
+    spec = SceneSpec()
+    white = spec.add("mat_diffuse", spec.add("tex_solid_rgb", 1.0, 1.0, 1.0), -1)
+    spec.add("world_add_object", spec.add("quad", (-6.0, 0.0, -6.0), (0.0, 0.0, 12.0), (12.0, 0.0, 0.0), white))
+    # (nothing touches anything: in the cusp between a resting sphere and the floor a path bounces until max_depth cuts it — seen)
+    spec.add("world_add_object", spec.add("sphere", 0.8, (-1.3, 1.5, 0.3), (-1.3, 1.5, 0.3), white))
+    spec.add("world_add_object", spec.add("cuboid", (0.4, 0.5, -0.8), (1.3, 1.8, 0.1), white))
+    P, I = icosphere(2)
+    P = (np.asarray(P, dtype=np.float64) + np.array([0.0, 5.5, 0.6])).astype(np.float32)     # (scaled by 0.6 below: centre (0, 3.3, 0.36))
+    spec.add("world_add_object", spec.add("mesh", 0.6, P, I, None, None, white))
+    spec.add("world_build")
+    spec.camera = default_camera(width=width, aspect=aspect, look_from=(0.0, 1.8, -5.5), look_at=(0.0, 0.9, 0.0), vfov=50.0,
+                                 env_color=(0.7, 0.8, 0.9))
+    return spec

@@ -513,6 +513,26 @@ def test_full_hd_scene6_properties(pt, det, ctx):
     gs.close(); os_.close()
 
 
+@pytest.mark.parametrize("width,aspect,spp", [(200, 1.0, 48), (1920, 16.0 / 9.0, 3)])
+def test_white_furnace_returns_the_environment_exactly(pt, ctx, width, aspect, spp):
+    """White furnace (tests/common.py white_furnace_scene): white diffuse floor, sphere, instanced cuboid and instanced mesh under a
+    constant environment, no lights — every pixel's mean is the environment's colour to rounding (1e-12 relative: up to fifty
+    factors of 1 +- 2^-52 per path), at a test size and at 1920x1080, through the default (dynamic) path and the static one.
+    Independent of the oracle: what it pins is sampler / pdf / eval consistency, the roulette, the environment term, regeneration
+    and the frame accumulator — an energy leak or a double count anywhere shows as a pixel that is not (0.7, 0.8, 0.9)."""
+    from common import white_furnace_scene
+    spec = white_furnace_scene(width, aspect)
+    gs = pt.Scene(ctx)
+    cam = spec.make_camera(pt.Camera, spec.replay(gs))
+    for k in (0, 1):
+        acc, st = gs.render(cam, 11, 0, spp, slots_per_pixel=k)
+        h = acc.shape[0]
+        assert acc.shape == (h, width, 3) and st.samples == h * width * spp
+        assert 1.0 < st.segments / st.samples < 6.0                  # paths do bounce (this is not an empty frame)
+        np.testing.assert_allclose(acc / spp, np.broadcast_to(np.array([0.7, 0.8, 0.9]), acc.shape), rtol=1e-12, atol=0)
+    gs.close()
+
+
 def test_cornell_1920_square_properties(pt, ctx):
     """Config 2's size (1920x1920, aspect 1.0: main.rs:218)."""
     gs = pt.Scene(ctx)

@@ -759,3 +759,21 @@ def test_float_hdr_images_keep_the_decoders_samples(orc, pt):
     assert {tuple(px) for px in out["f32"].reshape(-1, 3)} <= texels and out["f32"].max() >= 40.0
     assert out["u8"].max() <= 1.0
     assert {tuple(px) for px in out["u8"].reshape(-1, 3)} <= {tuple((1.0 / 255.0) * float(b) for b in np.round(np.clip(px, 0, 1) * 255)) for px in img.reshape(-1, 3)}
+
+
+def test_white_furnace_returns_the_environment_exactly(orc):
+    """The energy property the GPU suite checks at full size (tests/common.py white_furnace_scene), here on the oracle in both math
+    modes: white diffuse objects under a constant environment, no lights — every pixel mean is the environment's colour to rounding."""
+    from common import white_furnace_scene
+    spec = white_furnace_scene(72, 1.0)
+    for det_mode in (False, True):
+        orc.set_math_mode(det_mode)
+        try:
+            sc = orc.Scene()
+            cam = spec.make_camera(orc.Camera, spec.replay(sc))
+            acc, cnt = sc.render(cam, 11, 0, 12)
+            sc.close()
+        finally:
+            orc.set_math_mode(False)
+        assert 1.0 < cnt["segments"] / (72 * 72 * 12) < 6.0
+        np.testing.assert_allclose(acc / 12, np.broadcast_to(np.array([0.7, 0.8, 0.9]), acc.shape), rtol=1e-12, atol=0)
