@@ -616,6 +616,15 @@ __shared__ unsigned long long g_prof[N_CLASSES + 1][PROF_COLS];
 #define PT_DRAIN()
 #endif
 
+#ifndef PT_TAIL_SPLIT
+#define PT_TAIL_SPLIT 1             // 0: whole windows to the end of k_extend2's queue (A/B)
+#endif
+#ifndef PT_TAIL_PARTS
+#define PT_TAIL_PARTS 2             // rounds a tail window is handed out in (2: halves, 4: quarters)
+#endif
+#ifndef PT_TAIL_SPAN
+#define PT_TAIL_SPAN 1              // tail = the last PT_TAIL_SPAN windows per block launched
+#endif
 #ifndef PT_K2_REVERSE
 #define PT_K2_REVERSE 1
 #endif
@@ -676,6 +685,14 @@ __global__ __launch_bounds__(KB, MINB) void k_extend2(SceneD sc, PoolD pool, Cou
     const float t_min_f = __double2float_rd(t_min);
     unsigned long long nseg = 0;
     const uint32_t n_windows = pool.n_alloc / WIN;
+    // [r3] The queue's END is handed out in HALF windows (PT_TAIL_SPLIT): with ~16 windows per block and launch a block idles half a
+    // window on average while the last ones finish; the last gridDim.x windows go out as two rounds of four chunks each, so the spread
+    // at the launch's end is half as long: K2 -0.8 % on the 33.6 M-slot pool, -2.1 % on a 16.8 M-slot one (quarters: +2 %; the last TWO
+    // windows per block in halves: +1.4 %; both: +5 % — PT_TAIL_PARTS / PT_TAIL_SPAN)
+    constexpr uint32_t PARTS = PT_TAIL_SPLIT ? PT_TAIL_PARTS : 1, CH = (uint32_t)(WIN / KB) / PARTS;   // rounds per tail window, chunks per round
+    static_assert(PARTS * CH == (uint32_t)(WIN / KB), "");
+    const uint32_t n_tail = PT_TAIL_SPLIT ? (n_windows < gridDim.x * PT_TAIL_SPAN ? n_windows : gridDim.x * PT_TAIL_SPAN) : 0u;
+    const uint32_t n_full = n_windows - n_tail, n_queue = n_full + PARTS * n_tail;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt->win_shade = 0;
     if (ldu(&cnt->alive) == 0ull) return;   // (see k_extend)
 #ifdef PT_STAMPS
@@ -685,8 +702,10 @@ __global__ __launch_bounds__(KB, MINB) void k_extend2(SceneD sc, PoolD pool, Cou
     if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_extend, 1ull); s_nrays = 0; s_next = 0; }
     __syncthreads();
     for (;;) {
-        const uint32_t win = s_win;
-        if (win >= n_windows) break;
+        const uint32_t q = s_win;
+        if (q >= n_queue) break;
+        const uint32_t win = q < n_full ? q : n_full + (q - n_full) / PARTS;
+        const int j_lo = q < n_full ? 0 : (int)(((q - n_full) % PARTS) * CH), j_hi = q < n_full ? WIN / KB : j_lo + (int)CH;   // this round's chunks
         // [r3] K2 walks the pool from its END, k_shade from its beginning: each kernel starts on the windows the other touched last,
         // i.e. on what the 256 MB memory-side cache still holds of the 3-5 GB the previous launch streamed (PT_K2_REVERSE=0: A/B)
         const uint32_t wbase = (PT_K2_REVERSE ? n_windows - 1u - win : win) * WIN;
@@ -694,17 +713,17 @@ __global__ __launch_bounds__(KB, MINB) void k_extend2(SceneD sc, PoolD pool, Cou
         // ---- phase A: top level only ---------------------------------------------------------------
         // (PT_K2_PREFETCH: the ray of the NEXT chunk requested before this chunk's traversal starts)
 #if PT_K2_PREFETCH
-        uint32_t state_next = pool.bounce[wbase + threadIdx.x];
+        uint32_t state_next = pool.bounce[wbase + (uint32_t)j_lo * KB + threadIdx.x];
         RayD r_next{};
-        if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + threadIdx.x);
+        if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + (uint32_t)j_lo * KB + threadIdx.x);
 #endif
-        for (int j = 0; j < WIN / KB; ++j) {
+        for (int j = j_lo; j < j_hi; ++j) {
             const uint32_t sl = (uint32_t)j * KB + threadIdx.x;
 #if PT_K2_PREFETCH
             const uint32_t state = state_next;
             const bool alive = state < SLOT_IDLE;
             const RayD r = r_next;
-            if (j + 1 < WIN / KB) {
+            if (j + 1 < j_hi) {
                 state_next = pool.bounce[wbase + sl + KB];
                 if (state_next < SLOT_IDLE) r_next = load_ray(pool, wbase + sl + KB);
             }
@@ -883,9 +902,9 @@ __global__ __launch_bounds__(KB, MINB) void k_extend2(SceneD sc, PoolD pool, Cou
         {   // the window's result: one coalesced 4-byte store per slot; the eight PrimRef gathers (material class) go out together
             uint32_t word[WIN / KB];
 #pragma unroll
-            for (int j = 0; j < WIN / KB; ++j) word[j] = hit_word(sc, s_best_id[(uint32_t)j * KB + threadIdx.x]);
+            for (int j = 0; j < WIN / KB; ++j) word[j] = (j >= j_lo && j < j_hi) ? hit_word(sc, s_best_id[(uint32_t)j * KB + threadIdx.x]) : 0u;
 #pragma unroll
-            for (int j = 0; j < WIN / KB; ++j) stnt(&pool.hit_prim[wbase + (uint32_t)j * KB + threadIdx.x], word[j]);
+            for (int j = 0; j < WIN / KB; ++j) if (j >= j_lo && j < j_hi) stnt(&pool.hit_prim[wbase + (uint32_t)j * KB + threadIdx.x], word[j]);
         }
         if (threadIdx.x == 0) { s_win = (uint32_t)atomicAdd(&cnt->win_extend, 1ull); s_nrays = 0; s_next = 0; }   // all of this window's uses are behind the barrier above
         __syncthreads();   // LDS lists are reused by the next window
@@ -1312,6 +1331,9 @@ __global__ __launch_bounds__(KB, KB == BLOCK ? MINW : 1) void k_shade(SceneD sc,
         const int wave = (int)(threadIdx.x >> 6);
         __shared__ uint32_t s_win;
         const uint32_t n_windows = pool.n_alloc / WIN;
+        // (Handing the queue's END out in half windows, as k_extend2 does, was measured here too — the other half's slots counted as
+        // dead in the sort —: K3 +-0 on the 33.6 M-slot pool, +1.7 % on a 16.8 M-slot one (+2.4 % with the window's loads predicated): a half
+        // window pays the whole window's sort and barriers and levels its eight waves' end worse.)
         // The window index of the NEXT round is drawn by thread 0 when its wave has run out of groups and published by the
         // barrier that ends the window anyway: no barrier of its own, and the atomic's round trip (2-3 k cycles the whole
         // block used to sit out at the top of every window) runs while the other waves finish their groups.
