@@ -250,6 +250,8 @@ def main():
         if os.path.exists(pmc_path) and (args.scene, args.width, args.spp, world) == (6, 1920, 4000, 1):
             try:
                 pmc = json.load(open(pmc_path))
+                if pmc.get("resident_paths") not in (None, stats[0]["n_slots"]):
+                    raise ValueError("per-launch counters of another pool size")
                 traffic = pmc.get("k_extend" if ms_ext >= ms_sh else "k_shade", {}).get("hbm_bytes_per_launch")
                 traffic_source = f"profiles/pmc_latest.json ({pmc.get('source', 'earlier rocprofv3 --pmc passes of this command')}), not measured in this run"
             except Exception:

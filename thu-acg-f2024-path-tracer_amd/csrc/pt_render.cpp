@@ -223,8 +223,13 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         // [r3] about 64 samples per slot (was 128; 32 gained another 5-15 % on scene 6 below 500 spp but lost 4 % on scene 5 at 4K): re-measured for the sample ranges ONE RANK of an 8-GPU frame renders — scene 6
         // FHD @ 500 spp: 4.2 M slots 489 ms, 8.4 M (the old rule's choice) 426, 16.8 M 407.5, 33.6 M 409; @ 1000 spp: 8.4 M 846,
         // 16.8 M (old) 785.5, 33.6 M 779 — the long, thin end of a frame costs less than running the whole frame on a small pool.
+        // [r3, last afternoon] re-measured once more with the 512-thread K3, its 8192-slot windows and the half windows at the end of K2's
+        // queue (every launch's END costs less, so deeper pools pay): about 30 samples per slot and up to 512 K slots per CU — scene 6
+        // FHD @ 4000 spp: 33.6 M slots 2905, 67 M 2940, 134 M 2984, 268 M 2957 Msamples/s; @ 2000: 2886 / 2903 / 2923; @ 1000: 33.6 M 2822,
+        // 67 M 2836, 134 M 2752; @ 500: 16.8 M 2688, 33.6 M 2750, 67 M 2694; @ 250: 8.4 M 2484, 16.8 M 2574; scene 3 1920x1920 @ 4000:
+        // 1314 / 1328 / 1359; scene 5 4K @ 1000: 4355 / 4431 / 4499 (profiles/r03_pool_sweep.txt). 134 M slots are 14 GB of path records.
         uint64_t per_cu = 16384;   // a power of two (the tile-ordered work items and the 64 counter shards divide it evenly)
-        while (per_cu < 131072 && per_cu * 3 / 2 * (uint64_t)std::max(1, ctx->n_cus) * 64 <= total_work) per_cu *= 2;
+        while (per_cu < 524288 && per_cu * 2 * (uint64_t)std::max(1, ctx->n_cus) * 30 <= total_work) per_cu *= 2;
         uint64_t target = (uint64_t)ctx->n_cus * per_cu;
         if (const char* e = exp_env("PT_POOL_SLOTS")) {
             target = strtoull(e, nullptr, 10);
@@ -241,7 +246,8 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
     const uint32_t n_slots = (uint32_t)n_slots64;
     // one allocation: the two record arrays (RayRec, PathRec), the static mode's f64 arrays, the two u32 state arrays
     const size_t n_al = ((size_t)n_slots + 8191) & ~(size_t)8191;   // whole windows: 2048 slots (k_extend2, k_shade) / 4096 (k_shade with 512 threads)
-    const size_t bytes = n_al * (sizeof(RayRec) + sizeof(PathRec) + 6 * sizeof(double) + 2 * sizeof(uint32_t));
+    const size_t n_f64 = dynamic ? 0 : 6;   // the per-slot sample sums and radiances exist in the static mode only (the dynamic mode adds into the frame)
+    const size_t bytes = n_al * (sizeof(RayRec) + sizeof(PathRec) + n_f64 * sizeof(double) + 2 * sizeof(uint32_t));
     if (bytes > s->pool_bytes) {
         if (s->pool_mem) (void)hipFree(s->pool_mem);
         s->pool_mem = nullptr;
@@ -261,7 +267,7 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         pool.path = (PathRec*)m; m += n_al * sizeof(PathRec);
         double* d = (double*)m;
         double** f64s[6] = {&pool.ax, &pool.ay, &pool.az, &pool.rx, &pool.ry, &pool.rz};
-        for (auto p : f64s) { *p = d; d += n_al; }
+        for (auto p : f64s) { *p = n_f64 ? d : nullptr; d += n_f64 ? n_al : 0; }
         uint32_t* u = (uint32_t*)d;
         uint32_t** u32s[2] = {&pool.hit_prim, &pool.bounce};
         for (auto p : u32s) { *p = u; u += n_al; }

@@ -57,6 +57,7 @@ if m("k_init", "WRITE_SIZE"):
 if m("k_extend", "FETCH_SIZE"):
     cal["fetch_factor_first_extend"] = slots * (64 + 4) / (out["k_extend"]["FETCH_SIZE"]["first"] * 1024)   # first K2 launch: every slot alive
 out["calibration"] = cal
+out["resident_paths"] = slots   # the pool the per-launch figures belong to (bench.py attaches `traffic` only at the same pool size)
 FF = 2.0   # guide: FETCH_SIZE reads exactly 1/2 of wide coalesced streams on gfx950 (own calibration above: 1.7-1.8)
 for k in ("k_extend", "k_shade"):
     if k not in out:

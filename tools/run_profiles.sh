@@ -14,7 +14,11 @@ done
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/sq" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/sq.log" 2>&1; echo "sq rc=$?"
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/tcc" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/tcc.log" 2>&1; echo "tcc rc=$?"
 # the raw per-dispatch CSVs are large: keep the kernel stats and per-kernel means only
-python3 tools/pmc_summary.py "$OUT" "$TAG" 33554432 > "$OUT/pmc_summary.txt" 2>&1
+SLOTS=$(python3 -c "
+import json
+for l in open('$OUT/stats.log'):
+    if l.startswith('{'): print(json.loads(l)['config']['resident_paths']); break")
+python3 tools/pmc_summary.py "$OUT" "$TAG" ${SLOTS:-33554432} > "$OUT/pmc_summary.txt" 2>&1
 cp profiles/${TAG}_pmc_summary.json "$OUT/" 2>/dev/null
 cp "$OUT"/stats/*/*kernel_stats.csv "$OUT/${TAG}_bench_4000spp_kernel_stats.csv" 2>/dev/null
 grep -h '^{' "$OUT/stats.log" > "$OUT/${TAG}_bench_4000spp_under_rocprof.json"
