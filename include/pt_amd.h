@@ -40,8 +40,8 @@ typedef struct pt_camera {
 
 typedef struct pt_render_opts {
     uint32_t slots_per_pixel;   /* resident paths per pixel; 0 = auto (fills the GPU; about one path per 30 samples of the
-                                   frame, at most 512 K paths per CU: 134 M paths = 14 GB of device memory for 1920x1080 @
-                                   4000 spp on an MI355X, kept by the scene until pt_scene_destroy); 1 = the reference's
+                                   frame, at most 1 M paths per CU: 134 M paths = 14 GB of device memory for 1920x1080 @
+                                   4000 spp on an MI355X, 28 GB at most, kept by the scene until pt_scene_destroy); 1 = the reference's
                                    exact per-pixel sample order */
     uint32_t accum_on_device;   /* accum points to device memory (e.g. a torch tensor) */
     uint32_t profile;           /* time every kernel launch with HIP events */

@@ -230,6 +230,9 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         // 1314 / 1328 / 1359; scene 5 4K @ 1000: 4355 / 4431 / 4499 (profiles/r03_pool_sweep.txt). 134 M slots are 14 GB of path records.
         uint64_t per_cu = 16384;   // a power of two (the tile-ordered work items and the 64 counter shards divide it evenly)
         while (per_cu < 524288 && per_cu * 2 * (uint64_t)std::max(1, ctx->n_cus) * 30 <= total_work) per_cu *= 2;
+        // one more doubling (268 M slots, 28 GB) only from 48 samples per slot: scene 3 1920x1920 @ 4000 spp (55 per slot) 1335 -> 1362,
+        // while at 31 per slot scene 6 FHD @ 4000 loses 0.7 % and scene 5 4K @ 1000 0.5 % (initialising and compacting the pool costs 58 ms there)
+        if (per_cu == 524288 && per_cu * 2 * (uint64_t)std::max(1, ctx->n_cus) * 48 <= total_work) per_cu *= 2;
         uint64_t target = (uint64_t)ctx->n_cus * per_cu;
         if (const char* e = exp_env("PT_POOL_SLOTS")) {
             target = strtoull(e, nullptr, 10);
