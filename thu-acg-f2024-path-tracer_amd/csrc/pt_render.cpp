@@ -324,7 +324,10 @@ extern "C" int pt_render(pt_scene* s, const pt_camera* cam, uint64_t seed, uint3
         // four blocks per CU where the LDS allows it (stacks of 16 and 20 entries): the kernel then runs at 128 registers with
         // 64 B of spills per lane and is still 7.5 % faster than at three blocks and 149 registers (round 2; in round 1, at
         // 166 registers, the same bound meant 168 B of spills and lost 11 %)
-        int code = need <= 16 ? 164 : need <= 20 ? 204 : need <= 24 ? 243 : need <= 28 ? 283 : 323;
+        // [r3, last] stacks of <= 16 entries: blocks of 128 threads over 1024-slot windows (code 2164, eight blocks per CU) — with the
+        // queue's end in half windows the smaller block's shorter barrier waits win on every pool size: K2 -1.0 % (16.8 M slots), -1.8 %
+        // (67 M, 134 M) against 256 threads; 64 threads: +1 % / -2.0 % / -2.5 % (worse on shallow pools); 512 threads: +5 %
+        int code = need <= 16 ? 2164 : need <= 20 ? 204 : need <= 24 ? 243 : need <= 28 ? 283 : 323;
         if (const char* e = exp_env("PT_EXT2")) {
             const int c = atoi(e);
             if (c / 10 >= need && (c == 163 || c == 164 || c == 204 || c == 243 || c == 283 || c == 323)) code = c;
