@@ -249,7 +249,7 @@ def test_kernel_forms_and_pool_sizes_agree(pt, ctx):
     ref, st0 = render(1, 6)
     assert st0.extend_variant == 0                                   # two-phase kernel is the default with meshes
     for env in ({"PT_NO_FLAT_TLAS": "1"}, {"PT_K2": "batch"}, {"PT_K2": "batch", "PT_NO_FLAT_TLAS": "1"}, {"PT_EXT2": "243"}, {"PT_EXT2": "163"},
-                {"PT_SHADE_VARIANT": "2"}, {"PT_SHADE_VARIANT": "13"}, {"PT_SHADE_VARIANT": "12"}, {"PT_SHADE_VARIANT": "22"}, {"PT_SHADE_VARIANT": "32"},
+                {"PT_SHADE_VARIANT": "2"}, {"PT_SHADE_VARIANT": "13"}, {"PT_SHADE_VARIANT": "12"}, {"PT_SHADE_VARIANT": "22"}, {"PT_SHADE_VARIANT": "32"}, {"PT_SHADE_VARIANT": "52"},
                 {"PT_SHADE_VARIANT": "42", "PT_WIDE_WINDOW_MIN": "1"}, {"PT_EXT2": "1164"}, {"PT_EXT2": "164"}, {"PT_EXT2": "8164"}):
         env = dict(env, PT_EXPERIMENT="1")                          # the switches are inert without it
         acc, st = _with_env(env, lambda: render(1, 6))

@@ -1745,11 +1745,12 @@ static shade_fn pick_shade(int variant, bool lights) {   // variant = sort*10 + 
     case 13: return lights ? k_shade<true, 3, true> : k_shade<true, 3, false>;
     case 22: return lights ? k_shade<true, 2, true, 512> : k_shade<true, 2, false, 512>;
     case 32: case 42: return lights ? k_shade<true, 2, true, 512, 16> : k_shade<true, 2, false, 512, 16>;
+    case 52: return lights ? k_shade<true, 2, true, 256, 16> : k_shade<true, 2, false, 256, 16>;   // A/B: 256 threads over 4096-slot windows (window size vs block size)
     default: return lights ? k_shade<false, 2, true> : k_shade<false, 2, false>;
     }
 }
 static int shade_threads(int variant) { return variant == 22 || variant == 32 || variant == 42 ? 512 : BLOCK; }
-static int shade_window(int variant) { return variant == 32 ? 8192 : variant == 22 ? 4096 : SORT_WINDOW; }
+static int shade_window(int variant) { return variant == 32 ? 8192 : variant == 22 || variant == 52 ? 4096 : SORT_WINDOW; }
 void launch_shade(const SceneD& sc, const CamD& cam, const PoolD& pool, CountersD* cnt, uint64_t seed, int max_blocks, int variant,
                   hipStream_t st, uint32_t wide_window_min) {
     // 42: 8192-slot windows while the pool holds at least PT_WIDE_WINDOW_MIN of them per block launched, 4096-slot windows below
