@@ -649,7 +649,17 @@ constexpr int EXT_WINDOW = 2048;   // slots per block window
 #define PT_REFILL_MIN 16
 #endif
 constexpr uint32_t REFILL_MIN = PT_REFILL_MIN;   // idle lanes that trigger a refill of the wave in phase B
-constexpr int EXT_CAND = 768;      // candidate list of a window (LDS); a fuller window walks the rest in phase A
+#ifndef PT_EXT_CAND
+#define PT_EXT_CAND 768
+#endif
+#ifndef PT_EXT_CAND_SMALL
+#define PT_EXT_CAND_SMALL 1024
+#endif
+// Candidate list per 2048 slots (LDS; scaled with the block size); a fuller window walks the rest in phase A, one mesh after the other
+// inside the divergent top-level code — expensive: scene 6, 128-thread blocks: 512 entries K2 +8.6 %, 768 (37.5 % of the window, the
+// round-1 choice) the reference, 1024 -2.3 %. The 128-thread form has the LDS for 1024 (19.5 KB per block, eight blocks per CU); the
+// 256-thread forms with their deeper stacks stay at 768.
+constexpr int EXT_CAND = PT_EXT_CAND, EXT_CAND_SMALL = PT_EXT_CAND_SMALL;
 static_assert(EXT_WINDOW % BLOCK == 0 && EXT_WINDOW <= 65536, "k_extend2: s_cand_sl holds 16-bit slot offsets inside the window");
 static_assert(EXT_WINDOW == SORT_WINDOW_SLOTS, "the pool is allocated in whole windows of this size (pt_render.cpp rounds n_alloc to 2048)");
 
@@ -684,7 +694,7 @@ PT_DEV void blas_pass(const SceneD& sc, const RayD& wray, const Entry& e, double
 // KB: threads per block (256; [r3] other sizes for A/B — the window and the candidate list scale with it; MINB = waves per SIMD, which is what hipcc's launch bound means)
 template <int EXT_STACK, int MINB, int KB = BLOCK>
 __global__ __launch_bounds__(KB, MINB) void k_extend2(SceneD sc, PoolD pool, CountersD* cnt) {
-    constexpr int WIN = EXT_WINDOW / BLOCK * KB, CAND = EXT_CAND / BLOCK * KB;
+    constexpr int WIN = EXT_WINDOW / BLOCK * KB, CAND = (KB <= 128 ? EXT_CAND_SMALL : EXT_CAND) / BLOCK * KB;
     __shared__ uint32_t stack[EXT_STACK * KB];
     __shared__ uint32_t s_best_id[WIN];                            //  8 KB  closest primitive of every slot of the window
     __shared__ double s_cand_t[CAND];                              //  6 KB  candidates (rays that entered mesh boxes): phase-A best t,
